@@ -315,8 +315,10 @@ class Reference:
     def api_match(self, left, right, opt, reset=True):
         """Through the reference's public entry points only (what bench's cpu_baseline times)."""
         h, w = left.shape
-        if reset and not self.lib.SGM_Reset(w, h, C.byref(opt)):
-            return None
+        if reset:
+            self.lib.ref_clear_census()     # Q3: stale border values from an earlier shape
+            if not self.lib.SGM_Reset(w, h, C.byref(opt)):
+                return None
         out = np.empty((h, w), np.float32)
         ok = self.lib.SGM_Match(left.ctypes.data, right.ctypes.data, out.ctypes.data)
         return out if ok else None

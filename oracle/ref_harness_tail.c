@@ -14,6 +14,15 @@ int ref_capacity(int out[3])
 
 unsigned long ref_oob_count(void) { return ref_oob_dropped; }
 
+/* The reference never writes the 2-px census border and relies on zero-initialised statics (Q3):
+ * after a run at another width the buffers hold stale values there.  Call before SGM_Reset when
+ * the shape changed. */
+void ref_clear_census(void)
+{
+    memset(census_left_buffer, 0, sizeof census_left_buffer);
+    memset(census_right_buffer, 0, sizeof census_right_buffer);
+}
+
 static int ref_fits(uint16_t w, uint16_t h, const SGMOption* o)
 {
     return w <= MAX_IMG_WIDTH && h <= MAX_IMG_HEIGHT && (size_t)w * h <= (size_t)MAX_IMG_SIZE &&
@@ -28,8 +37,7 @@ int ref_run_stages(const uint8_t* left, const uint8_t* right, uint16_t w, uint16
     if (!ref_fits(w, h, opt)) return -1;
     ref_oob_dropped = 0;
     /* the reference relies on zero-initialised statics for the census border (Q3) */
-    memset(census_left_buffer, 0, sizeof census_left_buffer);
-    memset(census_right_buffer, 0, sizeof census_right_buffer);
+    ref_clear_census();
     if (!SGM_Reset(w, h, opt)) return -2;
     const size_t px = (size_t)w * h, cells = px * sgm.disp_range;
     sgm.img_left = left;

@@ -137,7 +137,7 @@ void sgmo_aggregate_dir(const uint8_t* img, const uint8_t* cost, int W, int H, i
 
     for (int line = 0; line < lines; ++line) {
         const int n = sgmo_path_walk(W, H, dx, dy, line, pix);
-        g_dropped += (uint64_t)(full - n);
+        g_dropped += (uint64_t)(n < full);     /* lines ended by the out-of-image guard */
 
         /* first pixel: L = C (ref :266-275) */
         size_t cell = (size_t)pix[0] * D;

@@ -108,7 +108,7 @@ bool      sgmo_match(sgmo_ctx* c, const uint8_t* left, const uint8_t* right, flo
  *        5 dispR(f32) 6 after LR(f32) 7 after speckle(f32) 8 final(f32). */
 const void* sgmo_stage(const sgmo_ctx* c, int which, size_t* bytes);
 
-/* Counters of the last match: [0] out-of-image steps dropped, [1] uint8 wraps of L_r (Q7). */
+/* Counters of the last match: [0] path lines ended by the out-of-image guard (Q6), [1] uint8 wraps of L_r (Q7). */
 void sgmo_counters(const sgmo_ctx* c, uint64_t out[2]);
 
 /* Synthetic stereo pair of SURVEY.md 8(d): LCG noise, 2x2 smoothing, slanted-plane disparity. */

@@ -1,0 +1,56 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle.pyoracle import Oracle
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def golden_cases():
+    with open(os.path.join(GOLDEN, "cases.json")) as f:
+        return {c["name"]: c for c in json.load(f)["cases"]}
+
+
+def option_from_dict(d):
+    from oracle.pyoracle import SGMOption
+    o = SGMOption()
+    for k, v in d.items():
+        setattr(o, k, v)
+    return o
+
+
+def load_npz(name):
+    with np.load(os.path.join(GOLDEN, name), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def case_inputs(case, oracle):
+    """Inputs of a golden case: stored arrays for tiny cases / cone, else regenerated from the seed
+    with the LCG generator and verified against the stored input digests."""
+    from oracle.pyoracle import sha
+    if case["name"] == "cone":
+        z = load_npz("cone_inputs.npz")
+        return z["left"], z["right"]
+    if "file" in case:
+        z = load_npz(case["file"])
+        return z["left"], z["right"]
+    l, r = oracle.synth_pair(case["w"], case["h"], case["d"], case["seed"])
+    assert sha(l) == case["sha256_inputs"]["left"] and sha(r) == case["sha256_inputs"]["right"]
+    return l, r
