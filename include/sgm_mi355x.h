@@ -1,0 +1,138 @@
+/*
+ * sgm_mi355x.h -- C-ABI of libsgm_mi355x.so, the MI355X (gfx950) drop-in for the reference's
+ * Semi-Global-Matching library.
+ *
+ * Part 1 is the reference boundary itself: the same three entry points with the same SGMOption
+ * layout, argument meaning and error behaviour as
+ *   /root/reference/SemiGlobalMatching/SemiGlobalMatching/SemiGlobalMatching.h:24-40 (SGMOption)
+ *   /root/reference/SemiGlobalMatching/SemiGlobalMatching/SemiGlobalMatching.h:78-80 (functions)
+ * so a caller such as the reference's main.c:72,83 links against this library unchanged.
+ *
+ * Part 2 are extensions the reference does not have (device-resident buffers, several
+ * independent instances, stage read-back for parity tests).  Plain C types only.
+ *
+ * Results: disparity in pixels with sub-pixel fraction, invalid = +INFINITY
+ * (SemiGlobalMatching.h:12), bit-identical to the reference's C code for every defined input
+ * (see DESIGN.md "Parity contract" for the one undefined behaviour of the reference that is
+ * defined here).
+ */
+#ifndef SGM_MI355X_H
+#define SGM_MI355X_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * Part 1 -- the reference boundary
+ * ---------------------------------------------------------------------------------------- */
+
+/* replaces SemiGlobalMatching.h:24-40; 28 bytes, align 4 on x86-64 SysV */
+typedef struct {
+    uint8_t  num_paths;          /* ignored by the reference (always 8 directions); see SGM_SetHonorNumPaths */
+    uint16_t min_disparity;
+    uint16_t max_disparity;      /* search range is [min_disparity, max_disparity) */
+
+    bool     is_check_unique;
+    float    uniqueness_ratio;
+
+    bool     is_check_lr;
+    float    lrcheck_thres;
+
+    bool     is_remove_speckles;
+    uint16_t min_speckle_area;
+
+    int16_t  p1;
+    int16_t  p2_init;
+} SGMOption;
+
+/* replaces SemiGlobalMatching.h:78 / SemiGlobalMatching.c:37-66.
+ * false for width==0, height==0, max_disparity<=min_disparity (as the reference) and, in addition,
+ * when no gfx950 device is usable, a HIP call fails, or the disparity range exceeds
+ * SGM_MAX_DISPARITY_RANGE (the reason is printed to stderr).  Sizes device buffers for this
+ * shape and marks the aggregated-cost volume as zero. */
+bool SGM_Initialize(uint16_t width, uint16_t height, const SGMOption* option);
+
+/* replaces SemiGlobalMatching.h:79 / SemiGlobalMatching.c:128-132 (clear + Initialize). */
+bool SGM_Reset(uint16_t width, uint16_t height, const SGMOption* option);
+
+/* replaces SemiGlobalMatching.h:80 / SemiGlobalMatching.c:68-125.
+ * img_left/img_right: host pointers, row-major uint8, stride = width, borrowed for the call.
+ * disp_left: host pointer to width*height floats, fully overwritten.  Blocking.
+ * false if not initialised or an image pointer is NULL (as the reference) or a HIP call failed.
+ * Like the reference a second SGM_Match without SGM_Reset accumulates onto the
+ * aggregated costs of the previous frame; call SGM_Reset per frame. */
+bool SGM_Match(const uint8_t* img_left, const uint8_t* img_right, float* disp_left);
+
+/* ------------------------------------------------------------------------------------------
+ * Part 2 -- extensions
+ * ---------------------------------------------------------------------------------------- */
+
+#define SGM_MAX_DISPARITY_RANGE 512
+
+/* The default instance used by Part 1 can be moved to another GPU of the node before
+ * SGM_Initialize (default: device 0, or the SGM_DEVICE environment variable). */
+bool SGM_SetDevice(int device_ordinal);
+
+/* 0 (default) = reference behaviour: num_paths is ignored, all 8 directions run.
+ * 1 = num_paths == 4 runs only the first four directions of SemiGlobalMatching.c:213-216.
+ * Takes effect at the next SGM_Initialize / SGM_Reset. */
+void SGM_SetHonorNumPaths(int honor);
+
+/* Same as SGM_Match but all three pointers are DEVICE pointers (HBM-resident frames) on the
+ * instance's device.  Asynchronous on the instance's stream; SGM_Synchronize waits. */
+bool SGM_MatchDevice(const uint8_t* d_left, const uint8_t* d_right, float* d_disp_left);
+bool SGM_Synchronize(void);
+
+/* Releases every device resource of the default instance (the reference has no counterpart). */
+void SGM_Shutdown(void);
+
+/* ---- explicit instances: several frames in flight on one GPU, one per HIP stream ---- */
+typedef struct sgm_instance sgm_instance;
+
+sgm_instance* sgm_create(int device_ordinal);                 /* NULL on failure */
+void          sgm_destroy(sgm_instance* s);
+void          sgm_set_honor_num_paths(sgm_instance* s, int honor);
+bool          sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMOption* option);
+bool          sgm_reset(sgm_instance* s, uint16_t width, uint16_t height, const SGMOption* option);
+bool          sgm_match(sgm_instance* s, const uint8_t* img_left, const uint8_t* img_right, float* disp_left);
+bool          sgm_match_device(sgm_instance* s, const uint8_t* d_left, const uint8_t* d_right, float* d_disp_left);
+bool          sgm_synchronize(sgm_instance* s);
+/* The HIP stream (hipStream_t as void*) the instance launches on, e.g. to record events. */
+void*         sgm_stream(sgm_instance* s);
+
+/* ---- stage read-back (parity tests; copies device -> host, blocking) ----
+ * which: 0 census left (u32 [H][W])       1 census right (u32 [H][W])
+ *        2 matching cost (u8 [H][W][D])   3 aggregated cost S (u16 [H][W][D])
+ *        4 left disparity after WTA       5 right-view disparity
+ *        6 after LR check                 7 after speckle removal        8 final (all f32 [H][W])
+ *        10..17 per-direction path cost L_r of direction (which-10) (u8 [H][W][D]; cells the
+ *               direction never visits read 0, cells visited twice hold the last-but-one visit)
+ * Returns the number of bytes written, 0 on error or if `capacity` is too small. */
+size_t sgm_read_stage(sgm_instance* s, int which, void* host_out, size_t capacity);
+size_t SGM_ReadStage(int which, void* host_out, size_t capacity);
+/* Stages 4, 6 and 7 are overwritten in place by the following stage; enable snapshots of them
+ * (three extra device-to-device copies per match) before the match whose stages are read. */
+void   sgm_keep_stages(sgm_instance* s, int enable);
+void   SGM_KeepStages(int enable);
+
+/* Per-kernel device time (ms) of the last match of the instance, measured with HIP events on
+ * the instance's stream when timing is enabled.  names[i] points to static strings.
+ * Returns the number of entries written (<= max_entries). */
+void   sgm_enable_timing(sgm_instance* s, int enable);
+int    sgm_last_timing(sgm_instance* s, const char** names, float* ms, int max_entries);
+
+/* Seeded synthetic stereo pair of SURVEY.md 8(d) (host buffers of width*height bytes each). */
+void   SGM_SynthPair(int width, int height, int disparity_range, uint32_t seed, uint8_t* left, uint8_t* right);
+
+/* Library build info, e.g. "sgm_mi355x 0.1 gfx950". */
+const char* SGM_Version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGM_MI355X_H */

@@ -1,0 +1,99 @@
+/*
+ * sgm_device.h -- the thin C interface between the C host (sgm_host.c) and the HIP translation
+ * unit (sgm_kernels.hip).  Plain C types only; device memory is passed as void*.
+ * Every function returns 0 on success and a non-zero HIP error code otherwise (the message is
+ * printed to stderr by the HIP side), except where noted.
+ */
+#ifndef SGM_DEVICE_H
+#define SGM_DEVICE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- device, stream, memory ---- */
+int   sgmd_device_count(void);                       /* <= 0: no usable device */
+int   sgmd_device_is_gfx950(int ordinal);            /* 1 yes, 0 no, <0 error */
+int   sgmd_stream_create(int ordinal, void** stream);
+int   sgmd_stream_destroy(int ordinal, void* stream);
+int   sgmd_stream_sync(int ordinal, void* stream);
+int   sgmd_alloc(int ordinal, void** dptr, size_t bytes);
+int   sgmd_free(int ordinal, void* dptr);
+int   sgmd_alloc_pinned(int ordinal, void** hptr, size_t bytes);
+int   sgmd_free_pinned(int ordinal, void* hptr);
+int   sgmd_h2d_async(int ordinal, void* stream, void* dst, const void* src, size_t bytes);
+int   sgmd_d2h_async(int ordinal, void* stream, void* dst, const void* src, size_t bytes);
+int   sgmd_d2d_async(int ordinal, void* stream, void* dst, const void* src, size_t bytes);
+int   sgmd_memset_async(int ordinal, void* stream, void* dst, int value, size_t bytes);
+
+/* ---- per-stage timing with HIP events on the stream ---- */
+int   sgmd_timer_create(int ordinal, void** timer, int max_marks);
+void  sgmd_timer_destroy(int ordinal, void* timer);
+int   sgmd_timer_mark(int ordinal, void* timer, void* stream, int index);           /* records event #index */
+int   sgmd_timer_elapsed(int ordinal, void* timer, int from, int to, float* ms);    /* after a sync */
+
+/* ---- geometry shared by all launchers ---- */
+typedef struct {
+    int W, H;          /* image */
+    int D;             /* max_disparity - min_disparity */
+    int Dp;            /* padded cell stride of the volumes: 16 * DPL >= D */
+    int DPL;           /* disparities per lane in the aggregation kernel (2,4,8,12,16,32) */
+    int dmin;          /* min_disparity */
+} sgmd_geom;
+
+/* one anomalous-line visit that lands on a pixel of row `row` (built by the host) */
+typedef struct {
+    int32_t col_slot;  /* column | (diagonal slot 0..3) << 16 */
+    int32_t step;      /* index k into the slot's extras rows */
+} sgmd_row_extra;
+
+typedef struct {
+    int ndirs;                 /* 4 or 8, reference order SemiGlobalMatching.c:213-220 */
+    int dx[8], dy[8];
+    int anom_line[8];          /* line index whose first step trips the wrong edge test, or -1 */
+    int ghost_zero;            /* 1: W >= H, the anomalous wave zeroes the cells no line visits */
+    int p1;
+} sgmd_paths;
+
+/* ---- stage launchers (all asynchronous on `stream`) ---- */
+
+/* 5x5 census of both images; border = 0.  SemiGlobalMatching.c:134-159 */
+int sgmd_census(int ord, void* stream, const sgmd_geom* g, const void* left, const void* right,
+                void* census_l, void* census_r);
+
+/* Hamming matching cost volume, u8 [H][W][Dp].  SemiGlobalMatching.c:161-196 */
+int sgmd_cost(int ord, void* stream, const sgmd_geom* g, const void* census_l, const void* census_r, void* cost);
+
+/* All directions of the path aggregation in ONE launch.  SemiGlobalMatching.c:198-372.
+ * planes: u8 [ndirs][H][W][Dp] per-direction path costs L_r; extras: u8 [4][H][Dp] path costs of
+ * the four anomalous diagonal lines (step-major); lut: u16[256] = (uint16)max(P1, P2/(a+1)). */
+int sgmd_aggregate(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* paths, const void* img_left,
+                   const void* cost, const void* lut, void* planes, size_t plane_bytes, void* extras);
+
+/* S = (accumulate ? S : 0) + sum of planes + anomalous-line visits.  u16 [H][W][Dp] */
+int sgmd_sum(int ord, void* stream, const sgmd_geom* g, int ndirs, const void* planes, size_t plane_bytes,
+             const void* extras, const void* row_extras, const void* row_extra_count, int row_cap,
+             int accumulate, void* S);
+
+/* left and right-view winner-take-all, uniqueness, sub-pixel.  SemiGlobalMatching.c:374-443 */
+int sgmd_wta(int ord, void* stream, const sgmd_geom* g, const void* S, int check_unique, float one_minus_ratio,
+             int want_right, void* disp_l, void* disp_r);
+
+/* SemiGlobalMatching.c:445-470 */
+int sgmd_lrcheck(int ord, void* stream, const sgmd_geom* g, void* disp_l, const void* disp_r, float thres);
+
+/* connected components (|delta| <= diff, 8-neighbourhood) smaller than min_area -> +INF.
+ * labels/sizes: int32 [H][W] scratch.  SemiGlobalMatching.c:585-642 */
+int sgmd_speckle(int ord, void* stream, const sgmd_geom* g, void* disp, float diff, unsigned min_area,
+                 void* labels, void* sizes);
+
+/* in-place raster-order 3x3 median (the reference calls MedianFilter with in == out, .c:120) */
+int sgmd_median(int ord, void* stream, const sgmd_geom* g, void* disp);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,601 @@
+/*
+ * sgm_host.c -- the C host of libsgm_mi355x.so.
+ *
+ * Implements the reference's library boundary (SGM_Initialize / SGM_Reset / SGM_Match,
+ * /root/reference/SemiGlobalMatching/SemiGlobalMatching/SemiGlobalMatching.h:78-80) plus the
+ * extensions of include/sgm_mi355x.h on top of the HIP stage launchers of sgm_device.h.
+ * This file owns everything that is not a kernel: option validation, buffer sizing, the
+ * adaptive-P2 table, the path-geometry tables for the anomalous diagonal lines and the order
+ * of the stages (the body of SGM_Match, SemiGlobalMatching.c:77-122).
+ *
+ * There is no CPU fallback: without a usable gfx950 device every entry point fails loudly.
+ */
+#include "../../include/sgm_mi355x.h"
+#include "sgm_device.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define SGM_VERSION_STRING "sgm_mi355x 0.1 (gfx950, hand-written HIP)"
+
+enum { T_CENSUS, T_COST, T_AGGREGATE, T_SUM, T_WTA, T_LRCHECK, T_SPECKLE, T_MEDIAN, T_COUNT };
+static const char* const k_stage_names[T_COUNT] = {"census", "cost", "aggregate", "sum", "wta", "lrcheck", "speckle", "median"};
+
+/* reference direction order, SemiGlobalMatching.c:213-220 */
+static const int k_dir_dx[8] = {1, -1, 0, 0, 1, -1, 1, -1};
+static const int k_dir_dy[8] = {0, 0, 1, -1, 1, -1, -1, 1};
+
+struct sgm_instance {
+    int device;
+    void* stream;
+    void* timer;
+    int timing;
+    int keep_stages;
+    int honor_num_paths;
+
+    bool initialized;
+    bool s_is_zero;              /* aggregated-cost volume logically zero (set by Initialize/Reset, Q14) */
+    SGMOption opt;
+    sgmd_geom g;
+    sgmd_paths paths;
+    int need_plane_memset;       /* W < H: diagonal planes are cleared before aggregation */
+    int row_cap;
+    float last_ms[T_COUNT];
+    bool have_ms;
+
+    /* device buffers (capacity tracked so a Reset with the same shape allocates nothing) */
+    size_t cap_px, cap_cells, cap_extras;
+    int cap_H, cap_row_cap;
+    int tab_W, tab_H, tab_ndirs, tab_p1, tab_p2;   /* what the uploaded tables were built for */
+    void *d_left, *d_right, *d_census_l, *d_census_r, *d_cost, *d_planes, *d_extras, *d_S;
+    void *d_disp, *d_disp_r, *d_labels, *d_sizes, *d_lut, *d_row_extras, *d_row_count;
+    void *d_snap_wta, *d_snap_lr, *d_snap_speckle;
+    size_t plane_bytes;
+    /* pinned staging for the host-pointer entry point */
+    void *h_left, *h_right, *h_disp;
+};
+
+#define FAIL(...)                                  \
+    do {                                           \
+        fprintf(stderr, "sgm_mi355x: " __VA_ARGS__); \
+        fputc('\n', stderr);                       \
+        return false;                              \
+    } while (0)
+
+/* ------------------------------------------------------------------ path geometry (host) */
+
+/* The reference's pointer walk (SemiGlobalMatching.c:243-255, 281-323, 359-367)
+ * for one line.  Writes visited linear pixel indices, returns their count; a step that leaves
+ * the image ends the line (the reference's undefined behaviour, defined away: SURVEY.md Q6). */
+static int walk_line(int W, int H, int dx, int dy, int line, int32_t* pix)
+{
+    const int fwd = (dx == 1 && dy == 0) || (dx == 0 && dy == 1) || (dx == 1 && dy == 1) || (dx == -1 && dy == 1);
+    const int s = fwd ? 1 : -1;
+    const long long npx = (long long)W * H;
+    long long p = (dy == 0) ? (long long)line * W + (fwd ? 0 : W - 1) : (fwd ? 0 : (long long)(H - 1) * W) + line;
+    const int steps = (dy == 0 ? W : H) - 1;
+    unsigned row = (unsigned)(fwd ? 0 : H - 1) & 0xFFFFu, col = (unsigned)line & 0xFFFFu;
+    int n = 0;
+    pix[n++] = (int32_t)p;
+    for (int j = 0; j < steps; ++j) {
+        if (dy == 0) p += s;
+        else if (dx == 0) p += (long long)s * W;
+        else {
+            const int not_last = fwd ? ((int)row < H - 1) : (row > 0);
+            if ((int)col == W - 1 && not_last) { p = ((long long)row + s) * W; col = 0; }
+            else if (col == 0 && not_last) { p = ((long long)row + s) * W + (W - 1); col = (unsigned)(W - 1); }
+            else p += (long long)s * (W + (dx == dy ? 1 : -1));
+        }
+        if (p < 0 || p >= npx) break;
+        pix[n++] = (int32_t)p;
+        row = (row + (unsigned)s) & 0xFFFFu;
+        col = (col + (unsigned)((dx == dy || dx == 0 || dy == 0) ? s : -s)) & 0xFFFFu;
+    }
+    return n;
+}
+
+/* exported for the host-logic tests (not part of the public header) */
+int sgm_host_walk_line(int W, int H, int dx, int dy, int line, int32_t* pix) { return walk_line(W, H, dx, dy, line, pix); }
+
+/* The line of a diagonal direction whose very first step trips the wrong edge test
+ * (SemiGlobalMatching.c:297,304 do not look at dx): it starts in column 0 while
+ * moving right, or in column W-1 while moving left. */
+static int anomalous_line(int W, int dx) { return dx > 0 ? 0 : W - 1; }
+int sgm_host_anomalous_line(int W, int dx) { return anomalous_line(W, dx); }
+
+/* (uint16) max(P1, P2 / (a + 1)), a = |grey difference| (SemiGlobalMatching.c:335) */
+static void build_p2_table(int p1, int p2_init, uint16_t* lut)
+{
+    for (int a = 0; a < 256; ++a) {
+        int pen = p2_init / (a + 1);
+        if (p1 > pen) pen = p1;
+        lut[a] = (uint16_t)pen;
+    }
+}
+void sgm_host_p2_table(int p1, int p2_init, uint16_t* lut) { build_p2_table(p1, p2_init, lut); }
+
+static int pick_dpl(int D)
+{
+    if (D <= 32) return 2;
+    if (D <= 64) return 4;
+    if (D <= 128) return 8;
+    if (D <= 192) return 12;
+    if (D <= 256) return 16;
+    return 32;
+}
+
+/* ------------------------------------------------------------------ instance management */
+
+static bool device_usable(int device)
+{
+    const int n = sgmd_device_count();
+    if (n <= 0) FAIL("no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= n) FAIL("device %d out of range (%d visible)", device, n);
+    if (sgmd_device_is_gfx950(device) != 1) FAIL("device %d is not gfx950 (MI355X); kernels are built for gfx950 only", device);
+    return true;
+}
+
+sgm_instance* sgm_create(int device)
+{
+    if (!device_usable(device)) return NULL;
+    sgm_instance* s = (sgm_instance*)calloc(1, sizeof *s);
+    if (!s) return NULL;
+    s->device = device;
+    if (sgmd_stream_create(device, &s->stream) != 0) { free(s); return NULL; }
+    return s;
+}
+
+static void free_device_buffers(sgm_instance* s)
+{
+    void** all[] = {&s->d_left, &s->d_right, &s->d_census_l, &s->d_census_r, &s->d_cost, &s->d_planes, &s->d_extras,
+                    &s->d_S, &s->d_disp, &s->d_disp_r, &s->d_labels, &s->d_sizes, &s->d_lut, &s->d_row_extras,
+                    &s->d_row_count, &s->d_snap_wta, &s->d_snap_lr, &s->d_snap_speckle};
+    for (size_t i = 0; i < sizeof all / sizeof all[0]; ++i) {
+        sgmd_free(s->device, *all[i]);
+        *all[i] = NULL;
+    }
+    sgmd_free_pinned(s->device, s->h_left);
+    sgmd_free_pinned(s->device, s->h_right);
+    sgmd_free_pinned(s->device, s->h_disp);
+    s->h_left = s->h_right = s->h_disp = NULL;
+    s->cap_px = s->cap_cells = s->cap_extras = 0;
+    s->cap_H = s->cap_row_cap = 0;
+    s->tab_W = s->tab_H = 0;
+}
+
+void sgm_destroy(sgm_instance* s)
+{
+    if (!s) return;
+    sgmd_stream_sync(s->device, s->stream);
+    free_device_buffers(s);
+    sgmd_timer_destroy(s->device, s->timer);
+    sgmd_stream_destroy(s->device, s->stream);
+    free(s);
+}
+
+void sgm_set_honor_num_paths(sgm_instance* s, int honor) { if (s) s->honor_num_paths = honor; }
+void sgm_keep_stages(sgm_instance* s, int enable) { if (s) s->keep_stages = enable; }
+void* sgm_stream(sgm_instance* s) { return s ? s->stream : NULL; }
+
+void sgm_enable_timing(sgm_instance* s, int enable)
+{
+    if (!s) return;
+    if (enable && !s->timer && sgmd_timer_create(s->device, &s->timer, T_COUNT + 1) != 0) return;
+    s->timing = enable;
+}
+
+int sgm_last_timing(sgm_instance* s, const char** names, float* ms, int max_entries)
+{
+    if (!s || !s->have_ms) return 0;
+    int n = 0;
+    for (int i = 0; i < T_COUNT && n < max_entries; ++i, ++n) {
+        if (names) names[n] = k_stage_names[i];
+        if (ms) ms[n] = s->last_ms[i];
+    }
+    return n;
+}
+
+/* Build the per-row table of anomalous-line visits and upload it together with the P2 table. */
+static bool upload_tables(sgm_instance* s)
+{
+    const int W = s->g.W, H = s->g.H;
+    uint16_t lut[256];
+    build_p2_table(s->opt.p1, s->opt.p2_init, lut);
+
+    int32_t* pix = (int32_t*)malloc(sizeof(int32_t) * (size_t)(W > H ? W : H));
+    int* count = (int*)calloc((size_t)H, sizeof(int));
+    int32_t* visits = (int32_t*)malloc(sizeof(int32_t) * 4 * (size_t)H);      /* [slot][k] pixel or -1 */
+    if (!pix || !count || !visits) { free(pix); free(count); free(visits); FAIL("out of host memory"); }
+    for (int i = 0; i < 4 * H; ++i) visits[i] = -1;
+    if (s->paths.ndirs > 4) {
+        for (int slot = 0; slot < 4; ++slot) {
+            const int d = 4 + slot;
+            const int n = walk_line(W, H, k_dir_dx[d], k_dir_dy[d], s->paths.anom_line[d], pix);
+            for (int k = 0; k < n; ++k) {
+                visits[slot * H + k] = pix[k];
+                count[pix[k] / W]++;
+            }
+        }
+    }
+    int cap = 1;
+    for (int r = 0; r < H; ++r) if (count[r] > cap) cap = count[r];
+    sgmd_row_extra* table = (sgmd_row_extra*)calloc((size_t)H * cap, sizeof *table);
+    if (!table) { free(pix); free(count); free(visits); FAIL("out of host memory"); }
+    memset(count, 0, sizeof(int) * (size_t)H);
+    for (int slot = 0; slot < 4; ++slot)
+        for (int k = 0; k < H; ++k) {
+            const int32_t p = visits[slot * H + k];
+            if (p < 0) continue;
+            const int r = p / W, c = p % W;
+            table[(size_t)r * cap + count[r]].col_slot = c | (slot << 16);
+            table[(size_t)r * cap + count[r]].step = k;
+            count[r]++;
+        }
+
+    bool ok = true;
+    if (cap > s->cap_row_cap || H > s->cap_H || !s->d_row_extras) {
+        sgmd_free(s->device, s->d_row_extras);
+        sgmd_free(s->device, s->d_row_count);
+        s->d_row_extras = s->d_row_count = NULL;
+        ok = sgmd_alloc(s->device, &s->d_row_extras, sizeof *table * (size_t)H * cap) == 0 &&
+             sgmd_alloc(s->device, &s->d_row_count, sizeof(int) * (size_t)H) == 0;
+        s->cap_row_cap = cap;
+        s->cap_H = H;
+    }
+    s->row_cap = cap;
+    /* plain blocking-safe uploads: the tables live on the host stack/heap only until the sync below */
+    ok = ok && sgmd_h2d_async(s->device, s->stream, s->d_row_extras, table, sizeof *table * (size_t)H * cap) == 0 &&
+         sgmd_h2d_async(s->device, s->stream, s->d_row_count, count, sizeof(int) * (size_t)H) == 0 &&
+         sgmd_h2d_async(s->device, s->stream, s->d_lut, lut, sizeof lut) == 0 &&
+         sgmd_stream_sync(s->device, s->stream) == 0;
+    free(table); free(visits); free(count); free(pix);
+    if (!ok) FAIL("uploading path tables failed");
+    return true;
+}
+
+static bool ensure_buffers(sgm_instance* s)
+{
+    const size_t px = (size_t)s->g.W * s->g.H;
+    const size_t cells = px * (size_t)s->g.Dp;
+    if (px <= s->cap_px && cells <= s->cap_cells && s->d_S) return true;
+    sgmd_stream_sync(s->device, s->stream);
+    free_device_buffers(s);
+    const int dev = s->device;
+    int rc = 0;
+    rc |= sgmd_alloc(dev, &s->d_left, px);
+    rc |= sgmd_alloc(dev, &s->d_right, px);
+    rc |= sgmd_alloc(dev, &s->d_census_l, px * 4);
+    rc |= sgmd_alloc(dev, &s->d_census_r, px * 4);
+    rc |= sgmd_alloc(dev, &s->d_cost, cells);
+    rc |= sgmd_alloc(dev, &s->d_planes, cells * 8);
+    rc |= sgmd_alloc(dev, &s->d_S, cells * 2);
+    rc |= sgmd_alloc(dev, &s->d_disp, px * 4);
+    rc |= sgmd_alloc(dev, &s->d_disp_r, px * 4);
+    rc |= sgmd_alloc(dev, &s->d_labels, px * 4);
+    rc |= sgmd_alloc(dev, &s->d_sizes, px * 4);
+    rc |= sgmd_alloc(dev, &s->d_lut, 512);
+    rc |= sgmd_alloc(dev, &s->d_snap_wta, px * 4);
+    rc |= sgmd_alloc(dev, &s->d_snap_lr, px * 4);
+    rc |= sgmd_alloc(dev, &s->d_snap_speckle, px * 4);
+    rc |= sgmd_alloc_pinned(dev, &s->h_left, px);
+    rc |= sgmd_alloc_pinned(dev, &s->h_right, px);
+    rc |= sgmd_alloc_pinned(dev, &s->h_disp, px * 4);
+    if (rc != 0) { free_device_buffers(s); FAIL("device allocation failed for %dx%dx%d", s->g.W, s->g.H, s->g.D); }
+    s->cap_px = px;
+    s->cap_cells = cells;
+    return true;
+}
+
+bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMOption* option)
+{
+    if (!s || !option) return false;
+    s->initialized = false;
+    s->opt = *option;                                            /* SemiGlobalMatching.c:41 */
+    if (width == 0 || height == 0) return false;                 /* .c:43 */
+    if (option->max_disparity <= option->min_disparity) return false;   /* .c:46 */
+    const int D = (uint16_t)(option->max_disparity - option->min_disparity);    /* .c:49 */
+    if (D > SGM_MAX_DISPARITY_RANGE) FAIL("disparity range %d exceeds SGM_MAX_DISPARITY_RANGE=%d", D, SGM_MAX_DISPARITY_RANGE);
+    if ((long long)width * height > 0x7FFFFFFFLL) FAIL("image too large (width*height must fit in 31 bits)");
+
+    s->g.W = width; s->g.H = height; s->g.D = D;
+    s->g.DPL = pick_dpl(D);
+    s->g.Dp = 16 * s->g.DPL;
+    s->g.dmin = option->min_disparity;
+
+    s->paths.ndirs = (s->honor_num_paths && option->num_paths == 4) ? 4 : 8;    /* Q1 */
+    s->paths.p1 = option->p1;
+    for (int d = 0; d < 8; ++d) {
+        s->paths.dx[d] = k_dir_dx[d];
+        s->paths.dy[d] = k_dir_dy[d];
+        s->paths.anom_line[d] = (d >= 4) ? anomalous_line(width, k_dir_dx[d]) : -1;
+    }
+    s->paths.ghost_zero = (width >= height);
+    s->need_plane_memset = !s->paths.ghost_zero;
+
+    if (!ensure_buffers(s)) return false;
+    /* extras: 4 anomalous lines x H steps x Dp bytes */
+    const size_t extras_bytes = (size_t)4 * height * s->g.Dp;
+    if (extras_bytes > s->cap_extras || !s->d_extras) {
+        sgmd_stream_sync(s->device, s->stream);
+        sgmd_free(s->device, s->d_extras);
+        s->d_extras = NULL;
+        if (sgmd_alloc(s->device, &s->d_extras, extras_bytes) != 0) FAIL("device allocation failed (extras)");
+        s->cap_extras = extras_bytes;
+    }
+    s->plane_bytes = (size_t)width * height * s->g.Dp;
+    /* a Reset with unchanged shape and penalties (the per-frame case, Q14) re-uploads nothing */
+    if (s->tab_W != width || s->tab_H != height || s->tab_ndirs != s->paths.ndirs || s->tab_p1 != option->p1 ||
+        s->tab_p2 != option->p2_init) {
+        if (!upload_tables(s)) return false;
+        s->tab_W = width; s->tab_H = height; s->tab_ndirs = s->paths.ndirs;
+        s->tab_p1 = option->p1; s->tab_p2 = option->p2_init;
+    }
+
+    s->s_is_zero = true;                                         /* .c:57: memset of cost_aggr, done lazily */
+    s->have_ms = false;
+    s->initialized = true;
+    return true;
+}
+
+bool sgm_reset(sgm_instance* s, uint16_t width, uint16_t height, const SGMOption* option)
+{
+    if (!s) return false;
+    s->initialized = false;                                      /* .c:130 */
+    return sgm_initialize(s, width, height, option);
+}
+
+static void mark(sgm_instance* s, int idx)
+{
+    if (s->timing && s->timer) sgmd_timer_mark(s->device, s->timer, s->stream, idx);
+}
+
+/* The body of SGM_Match (SemiGlobalMatching.c:80-122) on device buffers. */
+static bool run_pipeline(sgm_instance* s, const void* d_left, const void* d_right, void* d_out)
+{
+    const int dev = s->device;
+    void* st = s->stream;
+    const sgmd_geom* g = &s->g;
+    const SGMOption* o = &s->opt;
+    const size_t px_bytes = (size_t)g->W * g->H * sizeof(float);
+    int rc = 0;
+
+    mark(s, 0);
+    rc |= sgmd_census(dev, st, g, d_left, d_right, s->d_census_l, s->d_census_r);              /* .c:82-83 */
+    mark(s, 1);
+    rc |= sgmd_cost(dev, st, g, s->d_census_l, s->d_census_r, s->d_cost);                       /* .c:89 */
+    mark(s, 2);
+    if (s->need_plane_memset && s->paths.ndirs > 4)
+        rc |= sgmd_memset_async(dev, st, (char*)s->d_planes + 4 * s->plane_bytes, 0, 4 * s->plane_bytes);
+    rc |= sgmd_aggregate(dev, st, g, &s->paths, d_left, s->d_cost, s->d_lut, s->d_planes, s->plane_bytes,
+                         s->d_extras);                                                          /* .c:94 */
+    mark(s, 3);
+    rc |= sgmd_sum(dev, st, g, s->paths.ndirs, s->d_planes, s->plane_bytes, s->d_extras, s->d_row_extras,
+                   s->d_row_count, s->row_cap, s->s_is_zero ? 0 : 1, s->d_S);
+    s->s_is_zero = false;                                                                       /* Q14 */
+    mark(s, 4);
+    rc |= sgmd_wta(dev, st, g, s->d_S, o->is_check_unique ? 1 : 0, 1 - o->uniqueness_ratio,
+                   o->is_check_lr ? 1 : 0, d_out, s->d_disp_r);                                 /* .c:99,105 */
+    if (s->keep_stages) rc |= sgmd_d2d_async(dev, st, s->d_snap_wta, d_out, px_bytes);
+    mark(s, 5);
+    if (o->is_check_lr) rc |= sgmd_lrcheck(dev, st, g, d_out, s->d_disp_r, o->lrcheck_thres);   /* .c:109 */
+    if (s->keep_stages) rc |= sgmd_d2d_async(dev, st, s->d_snap_lr, d_out, px_bytes);
+    mark(s, 6);
+    if (o->is_remove_speckles)                                                                  /* .c:115 */
+        rc |= sgmd_speckle(dev, st, g, d_out, 1.0f, o->min_speckle_area, s->d_labels, s->d_sizes);
+    if (s->keep_stages) rc |= sgmd_d2d_async(dev, st, s->d_snap_speckle, d_out, px_bytes);
+    mark(s, 7);
+    rc |= sgmd_median(dev, st, g, d_out);                                                       /* .c:120 */
+    mark(s, 8);
+    if (rc != 0) FAIL("a kernel launch failed");
+    return true;
+}
+
+static void collect_timing(sgm_instance* s)
+{
+    if (!(s->timing && s->timer)) return;
+    for (int i = 0; i < T_COUNT; ++i)
+        if (sgmd_timer_elapsed(s->device, s->timer, i, i + 1, &s->last_ms[i]) != 0) return;
+    s->have_ms = true;
+}
+
+bool sgm_match_device(sgm_instance* s, const uint8_t* d_left, const uint8_t* d_right, float* d_disp_left)
+{
+    if (!s || !s->initialized) return false;                     /* .c:70 */
+    if (!d_left || !d_right) return false;                       /* .c:73 */
+    if (!d_disp_left) return false;
+    return run_pipeline(s, d_left, d_right, d_disp_left);
+}
+
+bool sgm_synchronize(sgm_instance* s)
+{
+    if (!s) return false;
+    if (sgmd_stream_sync(s->device, s->stream) != 0) return false;
+    collect_timing(s);
+    return true;
+}
+
+bool sgm_match(sgm_instance* s, const uint8_t* img_left, const uint8_t* img_right, float* disp_left)
+{
+    if (!s || !s->initialized) return false;                     /* .c:70 */
+    if (!img_left || !img_right) return false;                   /* .c:73 */
+    if (!disp_left) return false;
+    const size_t px = (size_t)s->g.W * s->g.H;
+    memcpy(s->h_left, img_left, px);
+    memcpy(s->h_right, img_right, px);
+    if (sgmd_h2d_async(s->device, s->stream, s->d_left, s->h_left, px) != 0) return false;
+    if (sgmd_h2d_async(s->device, s->stream, s->d_right, s->h_right, px) != 0) return false;
+    if (!run_pipeline(s, s->d_left, s->d_right, s->d_disp)) return false;
+    if (sgmd_d2h_async(s->device, s->stream, s->h_disp, s->d_disp, px * sizeof(float)) != 0) return false;
+    if (!sgm_synchronize(s)) return false;
+    memcpy(disp_left, s->h_disp, px * sizeof(float));            /* .c:122 */
+    return true;
+}
+
+/* ------------------------------------------------------------------ stage read-back */
+
+static size_t compact_volume(const sgm_instance* s, const void* padded, size_t elem, void* out)
+{
+    const size_t px = (size_t)s->g.W * s->g.H;
+    const char* src = (const char*)padded;
+    char* dst = (char*)out;
+    for (size_t p = 0; p < px; ++p)
+        memcpy(dst + p * s->g.D * elem, src + p * s->g.Dp * elem, (size_t)s->g.D * elem);
+    return px * s->g.D * elem;
+}
+
+size_t sgm_read_stage(sgm_instance* s, int which, void* host_out, size_t capacity)
+{
+    if (!s || !s->initialized || !host_out) return 0;
+    const size_t px = (size_t)s->g.W * s->g.H;
+    const void* src = NULL;
+    size_t elem = 0;
+    bool volume = false;
+    switch (which) {
+    case 0: src = s->d_census_l; elem = 4; break;
+    case 1: src = s->d_census_r; elem = 4; break;
+    case 2: src = s->d_cost; elem = 1; volume = true; break;
+    case 3: src = s->d_S; elem = 2; volume = true; break;
+    case 4: src = s->d_snap_wta; elem = 4; break;
+    case 5: src = s->d_disp_r; elem = 4; break;
+    case 6: src = s->d_snap_lr; elem = 4; break;
+    case 7: src = s->d_snap_speckle; elem = 4; break;
+    case 8: src = s->d_disp; elem = 4; break;
+    default:
+        if (which >= 10 && which < 10 + s->paths.ndirs) {
+            src = (const char*)s->d_planes + (size_t)(which - 10) * s->plane_bytes;
+            elem = 1; volume = true;
+        }
+    }
+    if (!src) return 0;
+    if ((which == 4 || which == 6 || which == 7) && !s->keep_stages) return 0;
+    const size_t need = volume ? px * s->g.D * elem : px * elem;
+    if (capacity < need) return 0;
+    if (sgmd_stream_sync(s->device, s->stream) != 0) return 0;
+    if (!volume) {
+        if (sgmd_d2h_async(s->device, s->stream, host_out, src, need) != 0) return 0;
+        if (sgmd_stream_sync(s->device, s->stream) != 0) return 0;
+        return need;
+    }
+    const size_t padded_bytes = px * s->g.Dp * elem;
+    void* tmp = malloc(padded_bytes);
+    if (!tmp) return 0;
+    size_t got = 0;
+    if (sgmd_d2h_async(s->device, s->stream, tmp, src, padded_bytes) == 0 && sgmd_stream_sync(s->device, s->stream) == 0)
+        got = compact_volume(s, tmp, elem, host_out);
+    free(tmp);
+    return got;
+}
+
+/* ------------------------------------------------------------------ the reference boundary */
+
+static sgm_instance* g_default;
+static int g_default_device = -1;
+static int g_default_honor;
+
+static int default_device(void)
+{
+    if (g_default_device >= 0) return g_default_device;
+    const char* e = getenv("SGM_DEVICE");
+    return (e && *e) ? atoi(e) : 0;
+}
+
+bool SGM_SetDevice(int device_ordinal)
+{
+    if (device_ordinal < 0) return false;
+    if (g_default && g_default->device != device_ordinal) {
+        sgm_destroy(g_default);
+        g_default = NULL;
+    }
+    g_default_device = device_ordinal;
+    return true;
+}
+
+void SGM_SetHonorNumPaths(int honor)
+{
+    g_default_honor = honor;
+    if (g_default) g_default->honor_num_paths = honor;
+}
+
+bool SGM_Initialize(uint16_t width, uint16_t height, const SGMOption* option)
+{
+    if (!option) return false;
+    /* argument errors are reported exactly like the reference, before any device is touched */
+    if (width == 0 || height == 0) { if (g_default) g_default->initialized = false; return false; }
+    if (option->max_disparity <= option->min_disparity) { if (g_default) g_default->initialized = false; return false; }
+    if (!g_default) {
+        g_default = sgm_create(default_device());
+        if (!g_default) return false;
+        g_default->honor_num_paths = g_default_honor;
+    }
+    return sgm_initialize(g_default, width, height, option);
+}
+
+bool SGM_Reset(uint16_t width, uint16_t height, const SGMOption* option)
+{
+    if (g_default) g_default->initialized = false;               /* SemiGlobalMatching.c:130 */
+    return SGM_Initialize(width, height, option);
+}
+
+bool SGM_Match(const uint8_t* img_left, const uint8_t* img_right, float* disp_left)
+{
+    if (!g_default) return false;
+    return sgm_match(g_default, img_left, img_right, disp_left);
+}
+
+bool SGM_MatchDevice(const uint8_t* d_left, const uint8_t* d_right, float* d_disp_left)
+{
+    if (!g_default) return false;
+    return sgm_match_device(g_default, d_left, d_right, d_disp_left);
+}
+
+bool SGM_Synchronize(void) { return g_default ? sgm_synchronize(g_default) : false; }
+
+void SGM_Shutdown(void)
+{
+    sgm_destroy(g_default);
+    g_default = NULL;
+}
+
+size_t SGM_ReadStage(int which, void* host_out, size_t capacity)
+{
+    return g_default ? sgm_read_stage(g_default, which, host_out, capacity) : 0;
+}
+
+void SGM_KeepStages(int enable)
+{
+    if (g_default) g_default->keep_stages = enable;
+}
+
+const char* SGM_Version(void) { return SGM_VERSION_STRING; }
+
+/* ------------------------------------------------------------------ synthetic input */
+
+static uint32_t lcg(uint32_t* s) { *s = *s * 1664525u + 1013904223u; return *s; }
+
+void SGM_SynthPair(int W, int H, int D, uint32_t seed, uint8_t* left, uint8_t* right)
+{
+    const size_t px = (size_t)W * H;
+    uint8_t* noise = (uint8_t*)malloc(px);
+    if (!noise) return;
+    uint32_t st = seed;
+    for (size_t i = 0; i < px; ++i) noise[i] = (uint8_t)(lcg(&st) >> 24);
+    for (int y = 0; y < H; ++y) {
+        const int yb = (y + 1 < H) ? y + 1 : H - 1;
+        for (int x = 0; x < W; ++x) {
+            const int xb = (x + 1 < W) ? x + 1 : W - 1;
+            const unsigned sum = noise[(size_t)y * W + x] + noise[(size_t)y * W + xb] + noise[(size_t)yb * W + x] +
+                                 noise[(size_t)yb * W + xb];
+            left[(size_t)y * W + x] = (uint8_t)((sum + 2) >> 2);
+        }
+    }
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const int shift = D / 16 + ((5 * D / 8) * y) / H + 4 * ((x >> 6) & 1);
+            int v = (x + shift < W) ? left[(size_t)y * W + x + shift] : (int)(lcg(&st) >> 24);
+            v += (int)((lcg(&st) >> 24) & 3u) - 1;
+            right[(size_t)y * W + x] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    free(noise);
+}

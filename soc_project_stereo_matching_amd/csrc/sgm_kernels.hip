@@ -1,0 +1,1036 @@
+// sgm_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the SGM hot path and their
+// extern "C" launchers (interface: sgm_device.h).  No MFMA: the path is integer min-plus and
+// byte streaming, bounded by HBM bandwidth and by the length of the serial path recurrences.
+//
+// Data layout in HBM (all row-major, disparity fastest, Dp = padded disparity stride):
+//   census  u32 [H][W]            cost   u8  [H][W][Dp]
+//   planes  u8  [dir][H][W][Dp]   (per-direction path cost L_r, written once, never RMW)
+//   extras  u8  [4][H][Dp]        (L_r of the 4 anomalous diagonal lines, step-major)
+//   S       u16 [H][W][Dp]        disparity maps f32 [H][W]
+//
+// Reference for every stage: /root/reference/SemiGlobalMatching/SemiGlobalMatching/SemiGlobalMatching.c
+// (line numbers in the comments below refer to that file).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <math.h>
+#include <string.h>
+
+#include "sgm_device.h"
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            fprintf(stderr, "sgm_mi355x: %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e_), \
+                    __FILE__, __LINE__);                                                      \
+            return (int)e_;                                                                   \
+        }                                                                                     \
+    } while (0)
+
+// ============================================================================================
+// small device helpers
+// ============================================================================================
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));   // two u16 in one VGPR (v_pk_*_u16)
+
+static __device__ __forceinline__ unsigned as_u(us2 v) { return __builtin_bit_cast(unsigned, v); }
+static __device__ __forceinline__ us2 as_p(unsigned v) { return __builtin_bit_cast(us2, v); }
+static __device__ __forceinline__ us2 pk_min(us2 a, us2 b) { return __builtin_elementwise_min(a, b); }
+static __device__ __forceinline__ us2 splat(unsigned v) { return as_p((v & 0xFFFFu) * 0x00010001u); }
+
+// DPP cross-lane moves inside a 16-lane row (one VALU op, no LDS).  Lanes whose source lane does
+// not exist keep `old` (bound_ctrl = 0), which is how the 255 sentinels of ref :260-263 appear.
+template <int CTRL>
+static __device__ __forceinline__ unsigned dpp_mov(unsigned old, unsigned src)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)src, CTRL, 0xF, 0xF, false);
+}
+enum : int {
+    DPP_QUAD_XOR1 = 0xB1,        // quad_perm [1,0,3,2]
+    DPP_QUAD_XOR2 = 0x4E,        // quad_perm [2,3,0,1]
+    DPP_ROW_SHL1 = 0x101,        // lane i <- lane i+1 (within the row)
+    DPP_ROW_SHR1 = 0x111,        // lane i <- lane i-1
+    DPP_ROW_MIRROR = 0x140,      // lane i <- lane 15-i
+    DPP_ROW_HALF_MIRROR = 0x141  // lane i <- lane 7-i (within each 8)
+};
+
+// min over the 16 lanes of a row, result in every lane of the row (4 DPP ops)
+static __device__ __forceinline__ unsigned row_allmin(unsigned v)
+{
+    v = min(v, dpp_mov<DPP_QUAD_XOR1>(v, v));
+    v = min(v, dpp_mov<DPP_QUAD_XOR2>(v, v));
+    v = min(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v, v));
+    v = min(v, dpp_mov<DPP_ROW_MIRROR>(v, v));
+    return v;
+}
+
+// ============================================================================================
+// census 5x5  (ref :134-159)
+// ============================================================================================
+
+__global__ __launch_bounds__(256) void sgm_census_k(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
+                                                    uint32_t* __restrict__ cl, uint32_t* __restrict__ cr, int W, int H)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const uint8_t* img = blockIdx.z ? right : left;
+    uint32_t* out = blockIdx.z ? cr : cl;
+    uint32_t bits = 0;
+    // border of 2 px is never written by the reference (zero-initialised statics, Q3); also nothing
+    // at all is written for images with W <= 5 or H <= 5 (ref :136)
+    if (W > 5 && H > 5 && x >= 2 && x < W - 2 && y >= 2 && y < H - 2) {
+        const unsigned centre = img[(size_t)y * W + x];
+#pragma unroll
+        for (int r = -2; r <= 2; ++r)
+#pragma unroll
+            for (int c = -2; c <= 2; ++c) bits = (bits << 1) | (unsigned)(img[(size_t)(y + r) * W + (x + c)] < centre);
+    }
+    out[(size_t)y * W + x] = bits;
+}
+
+// ============================================================================================
+// matching cost  (ref :161-196): one thread = 16 consecutive disparities of one pixel
+// ============================================================================================
+
+__global__ __launch_bounds__(256) void sgm_cost_k(const uint32_t* __restrict__ cl, const uint32_t* __restrict__ cr,
+                                                  uint8_t* __restrict__ cost, int W, int H, int D, int Dp, int dmin)
+{
+    const int chunks = Dp >> 4;                       // Dp is a multiple of 32
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)W * H * chunks;
+    if (t >= total) return;
+    const int chunk = (int)(t % chunks);
+    const long long pix = t / chunks;
+    const int x = (int)(pix % W);
+    const uint32_t a = cl[pix];
+    const uint32_t* rrow = cr + (pix - x);
+    unsigned w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned word = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int di = chunk * 16 + q * 4 + b;    // index into the volume
+            const int xr = x - (dmin + di);
+            unsigned c = 127u;                        // off-image: UINT8_MAX/2 (ref :170-171)
+            if (di < D && xr >= 0 && xr < W) c = (unsigned)__popc(a ^ rrow[xr]);
+            word |= c << (8 * b);
+        }
+        w[q] = word;
+    }
+    *reinterpret_cast<uint4*>(cost + pix * Dp + chunk * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// ============================================================================================
+// path aggregation  (ref :198-372)
+//
+// One wave = 4 path lines (one per 16-lane DPP row); lane `sub` of a row owns DPL consecutive
+// disparities, kept as DPL/2 packed u16 pairs.  Per step and line:
+//   L(d) = u8( C(d) + min( Lp(d), Lp(d-1)+P1, Lp(d+1)+P1, minPrev + pen ) - minPrev )
+// with Lp(-1) = Lp(D) = 255 (ref :260-263), all sums truncated to u16 as in the C (ref :332-335)
+// and the result truncated to u8 (ref :343, Q7).  d+-1 neighbours of the lane-edge elements come
+// from DPP row shifts; min over d is an in-lane tree plus a 4-step DPP all-reduce.  All
+// directions run in one launch; every line walks the image with the reference's own pointer
+// state machine (ref :281-323, 359-367), so wrap-around diagonals (Q5) need no special casing.
+// ============================================================================================
+
+struct AggArgs {
+    const uint8_t* img;
+    const uint8_t* cost;
+    const uint16_t* lut;        // (uint16) max(P1, P2 / (|dg| + 1)), 256 entries (ref :335)
+    uint8_t* planes;
+    size_t plane_bytes;
+    uint8_t* extras;
+    int W, H, D, Dp;
+    int p1;
+    int ndirs;
+    int dx[8], dy[8];
+    int anom_line[8];
+    int block_begin[9];
+    int ghost_zero;
+};
+
+template <int DPL> struct CellVec { unsigned w[(DPL + 3) / 4]; };
+
+template <int DPL>
+static __device__ __forceinline__ void load_cells(const uint8_t* p, CellVec<DPL>& v)
+{
+    if constexpr (DPL == 2) {
+        v.w[0] = *reinterpret_cast<const unsigned short*>(p);
+    } else if constexpr (DPL == 4) {
+        v.w[0] = *reinterpret_cast<const unsigned*>(p);
+    } else if constexpr (DPL == 8) {
+        const uint2 t = *reinterpret_cast<const uint2*>(p);
+        v.w[0] = t.x; v.w[1] = t.y;
+    } else if constexpr (DPL == 12) {
+        struct __attribute__((packed, aligned(4))) u3 { unsigned a, b, c; };
+        const u3 t = *reinterpret_cast<const u3*>(p);
+        v.w[0] = t.a; v.w[1] = t.b; v.w[2] = t.c;
+    } else if constexpr (DPL == 16) {
+        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        v.w[0] = t.x; v.w[1] = t.y; v.w[2] = t.z; v.w[3] = t.w;
+    } else {
+        static_assert(DPL == 32, "unsupported DPL");
+        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        const uint4 u = *reinterpret_cast<const uint4*>(p + 16);
+        v.w[0] = t.x; v.w[1] = t.y; v.w[2] = t.z; v.w[3] = t.w;
+        v.w[4] = u.x; v.w[5] = u.y; v.w[6] = u.z; v.w[7] = u.w;
+    }
+}
+
+template <int DPL>
+static __device__ __forceinline__ void store_cells(uint8_t* p, const CellVec<DPL>& v)
+{
+    if constexpr (DPL == 2) {
+        *reinterpret_cast<unsigned short*>(p) = (unsigned short)v.w[0];
+    } else if constexpr (DPL == 4) {
+        *reinterpret_cast<unsigned*>(p) = v.w[0];
+    } else if constexpr (DPL == 8) {
+        *reinterpret_cast<uint2*>(p) = make_uint2(v.w[0], v.w[1]);
+    } else if constexpr (DPL == 12) {
+        struct __attribute__((packed, aligned(4))) u3 { unsigned a, b, c; };
+        u3 t; t.a = v.w[0]; t.b = v.w[1]; t.c = v.w[2];
+        *reinterpret_cast<u3*>(p) = t;
+    } else if constexpr (DPL == 16) {
+        *reinterpret_cast<uint4*>(p) = make_uint4(v.w[0], v.w[1], v.w[2], v.w[3]);
+    } else {
+        *reinterpret_cast<uint4*>(p) = make_uint4(v.w[0], v.w[1], v.w[2], v.w[3]);
+        *reinterpret_cast<uint4*>(p + 16) = make_uint4(v.w[4], v.w[5], v.w[6], v.w[7]);
+    }
+}
+
+// bytes -> packed u16 pairs and back (v_perm_b32)
+template <int DPL>
+static __device__ __forceinline__ void unpack_cells(const CellVec<DPL>& v, us2 (&pr)[DPL / 2])
+{
+#pragma unroll
+    for (int j = 0; j < DPL / 2; ++j) {
+        const unsigned w = v.w[j >> 1];
+        pr[j] = as_p(__builtin_amdgcn_perm(w, w, (j & 1) ? 0x0c030c02u : 0x0c010c00u));
+    }
+}
+template <int DPL>
+static __device__ __forceinline__ void pack_cells(const us2 (&pr)[DPL / 2], CellVec<DPL>& v)
+{
+    if constexpr (DPL == 2) {
+        v.w[0] = __builtin_amdgcn_perm(0u, as_u(pr[0]), 0x0c0c0200u);
+    } else {
+#pragma unroll
+        for (int k = 0; k < DPL / 4; ++k)
+            v.w[k] = __builtin_amdgcn_perm(as_u(pr[2 * k + 1]), as_u(pr[2 * k]), 0x06040200u);
+    }
+}
+
+// The reference's pointer walk for one line (ref :243-255 start, :281-323 step, :359-367 trackers).
+struct PathCursor {
+    int p;          // linear pixel index
+    int row, col;   // the two uint16_t trackers of the reference
+    bool dead;      // the walk left the image (Q6): the line ends
+};
+
+template <int DPL, bool PAD>
+__global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
+{
+    constexpr int NP = DPL / 2;     // packed pairs per lane
+    constexpr int PF = 4;           // software prefetch depth (steps)
+
+    __shared__ unsigned short lut_s[256];
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lut_s[lane * 4 + i] = a.lut[lane * 4 + i];
+    __syncthreads();
+
+    // which direction does this block belong to (wave-uniform)
+    const int b = blockIdx.x;
+    int dir = 0;
+    while (dir + 1 < a.ndirs && b >= a.block_begin[dir + 1]) ++dir;
+    const int grp = b - a.block_begin[dir];
+    const int dx = a.dx[dir], dy = a.dy[dir];
+    const int W = a.W, H = a.H, Dp = a.Dp;
+    const bool fwd = (dx == 1 && dy == 0) || (dx == 0 && dy == 1) || (dx == 1 && dy == 1) || (dx == -1 && dy == 1);  // ref :232
+    const int s = fwd ? 1 : -1;
+    const bool horizontal = (dy == 0), vertical = (dx == 0);
+    const int diag_step = s * (W + ((dx == dy) ? 1 : -1));        // ref :311-322
+    const int col_step = (dx == dy) ? s : -s;                      // ref :360-367
+    const int nlines = horizontal ? H : W;                         // ref :238
+    const int nsteps = (horizontal ? W : H) - 1;                   // ref :281
+    const int npx = W * H;
+
+    const int sub = lane & 15;
+    int line = grp * 4 + (lane >> 4);
+    const bool active = line < nlines;
+    if (!active) line = nlines - 1;                                // keep the wave convergent; stores are masked
+    const bool anom = active && (line == a.anom_line[dir]);
+    const int slot = dir - 4;                                      // diagonal slot of the extras buffer
+
+    uint8_t* const plane = a.planes + (size_t)dir * a.plane_bytes;
+    const int lane_off = sub * DPL;
+
+    // padded disparity slots (d >= D) are forced to 255: neutral for the min and exactly the
+    // Lp(D) sentinel the last real disparity needs
+    us2 padmask[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const unsigned lo = (lane_off + 2 * j >= a.D) ? 0x00FFu : 0u;
+        const unsigned hi = (lane_off + 2 * j + 1 >= a.D) ? 0x00FF0000u : 0u;
+        padmask[j] = as_p(lo | hi);
+    }
+
+    PathCursor fc;
+    if (horizontal) fc.p = line * W + (fwd ? 0 : W - 1);
+    else            fc.p = (fwd ? 0 : (H - 1) * W) + line;
+    fc.row = fwd ? 0 : H - 1;
+    fc.col = line;
+    fc.dead = false;
+
+    auto advance = [&](PathCursor& c) {
+        if (horizontal) {
+            c.p += s;
+        } else if (vertical) {
+            c.p += s * W;
+        } else {
+            const bool not_last = fwd ? (c.row < H - 1) : (c.row > 0);
+            if (c.col == W - 1 && not_last)      { c.p = (c.row + s) * W;           c.col = 0; }
+            else if (c.col == 0 && not_last)     { c.p = (c.row + s) * W + (W - 1); c.col = W - 1; }
+            else                                 { c.p += diag_step; }
+            c.row = (c.row + s) & 0xFFFF;
+            c.col = (c.col + col_step) & 0xFFFF;
+        }
+        if (c.p < 0 || c.p >= npx) c.dead = true;                  // only anomalous lines can get here
+    };
+
+    // where the L_r of step k goes: the direction's plane, or (anomalous line) the extras row k
+    auto out_ptr = [&](int p, int k) -> uint8_t* {
+        return anom ? a.extras + ((size_t)slot * H + k) * Dp + lane_off : plane + (size_t)p * Dp + lane_off;
+    };
+    // cells no regular line of this direction visits (the track the anomalous line should have
+    // taken) are zeroed by the anomalous line's lanes
+    auto ghost_zero = [&](int k) {
+        if (anom && a.ghost_zero) {
+            int gc = line + dx * k;
+            if (gc >= W) gc -= W;
+            if (gc < 0) gc += W;
+            const int gr = fwd ? k : H - 1 - k;
+            CellVec<DPL> z;
+#pragma unroll
+            for (int i = 0; i < (DPL + 3) / 4; ++i) z.w[i] = 0;
+            store_cells<DPL>(plane + ((size_t)gr * W + gc) * Dp + lane_off, z);
+        }
+    };
+
+    // ---- first pixel of the line: L = C (ref :266-275) ----
+    us2 Lp[NP];
+    unsigned min_prev;
+    int g_prev;
+    {
+        CellVec<DPL> c0;
+        load_cells<DPL>(a.cost + (size_t)fc.p * Dp + lane_off, c0);
+        g_prev = a.img[fc.p];
+        unpack_cells<DPL>(c0, Lp);
+        if (PAD) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) Lp[j] = as_p(as_u(Lp[j]) | as_u(padmask[j]));
+        }
+        us2 m = Lp[0];
+#pragma unroll
+        for (int j = 1; j < NP; ++j) m = pk_min(m, Lp[j]);
+        min_prev = row_allmin(min(as_u(m) & 0xFFFFu, as_u(m) >> 16));
+        if (active) {
+            CellVec<DPL> o;
+            pack_cells<DPL>(Lp, o);
+            store_cells<DPL>(out_ptr(fc.p, 0), o);
+        }
+        ghost_zero(0);
+    }
+
+    // ---- prefetch ring: cost cells, grey value and pixel index of the next PF steps ----
+    CellVec<DPL> cb[PF];
+    int gb[PF], pb[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        pb[u] = -1; gb[u] = 0;
+#pragma unroll
+        for (int i = 0; i < (DPL + 3) / 4; ++i) cb[u].w[i] = 0;
+        if (1 + u <= nsteps) {
+            if (!fc.dead) advance(fc);
+            pb[u] = fc.dead ? -1 : fc.p;
+            const int q = fc.dead ? 0 : fc.p;
+            load_cells<DPL>(a.cost + (size_t)q * Dp + lane_off, cb[u]);
+            gb[u] = a.img[q];
+        }
+    }
+
+    const us2 p1v = splat((unsigned)a.p1);
+    bool line_dead = false;
+
+    for (int k0 = 1; k0 <= nsteps; k0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int k = k0 + u;
+            if (k <= nsteps) {                                      // wave-uniform
+                const int p = pb[u];
+                const int g = gb[u];
+                us2 C[NP];
+                unpack_cells<DPL>(cb[u], C);
+                // refill this ring slot for step k + PF
+                if (k + PF <= nsteps) {
+                    if (!fc.dead) advance(fc);
+                    pb[u] = fc.dead ? -1 : fc.p;
+                    const int q = fc.dead ? 0 : fc.p;
+                    load_cells<DPL>(a.cost + (size_t)q * Dp + lane_off, cb[u]);
+                    gb[u] = a.img[q];
+                }
+                if (p < 0) line_dead = true;                        // Q6: the line ended
+
+                const int dg = g > g_prev ? g - g_prev : g_prev - g;
+                const us2 l4 = splat(min_prev + (unsigned)lut_s[dg]);         // ref :335, truncated to u16
+                const us2 mp = splat(min_prev);
+
+                // d-1 / d+1 neighbours across the lane boundary; 255 where there is none (ref :260-263)
+                const unsigned from_left = dpp_mov<DPP_ROW_SHR1>(0x00FF00FFu, as_u(Lp[NP - 1]));
+                const unsigned from_right = dpp_mov<DPP_ROW_SHL1>(0x00FF00FFu, as_u(Lp[0]));
+
+                us2 Ln[NP];
+#pragma unroll
+                for (int j = 0; j < NP; ++j) {
+                    const unsigned below = (j == 0) ? from_left : as_u(Lp[j - 1]);
+                    const unsigned above = (j == NP - 1) ? from_right : as_u(Lp[j + 1]);
+                    const us2 dm1 = as_p(__builtin_amdgcn_alignbit(as_u(Lp[j]), below, 16));   // (Lp(d-1), Lp(d))   pairs
+                    const us2 dp1 = as_p(__builtin_amdgcn_alignbit(above, as_u(Lp[j]), 16));   // (Lp(d+1), Lp(d+2))
+                    us2 m = pk_min(dm1 + p1v, dp1 + p1v);           // l2, l3 (ref :333-334), u16 wrap
+                    m = pk_min(m, Lp[j]);                           // l1
+                    m = pk_min(m, l4);
+                    const us2 wide = C[j] + m - mp;                 // mod 2^16 == the C's int arithmetic mod 2^16
+                    unsigned r = as_u(wide) & 0x00FF00FFu;          // ref :343 uint8 truncation (Q7)
+                    if (PAD) r |= as_u(padmask[j]);
+                    Ln[j] = as_p(r);
+                }
+                us2 m = Ln[0];
+#pragma unroll
+                for (int j = 1; j < NP; ++j) m = pk_min(m, Ln[j]);
+                min_prev = row_allmin(min(as_u(m) & 0xFFFFu, as_u(m) >> 16));   // ref :347,353
+#pragma unroll
+                for (int j = 0; j < NP; ++j) Lp[j] = Ln[j];
+                g_prev = g;
+
+                if (active && !line_dead) {
+                    CellVec<DPL> o;
+                    pack_cells<DPL>(Ln, o);
+                    store_cells<DPL>(out_ptr(p, k), o);
+                }
+                ghost_zero(k);
+            }
+        }
+    }
+}
+
+// ============================================================================================
+// S = [S +] sum over directions of L_r (+ the second visits of the anomalous lines)
+// ============================================================================================
+
+__global__ __launch_bounds__(256) void sgm_sum_k(const uint8_t* __restrict__ planes, size_t plane_bytes, int ndirs,
+                                                 const uint8_t* __restrict__ extras,
+                                                 const sgmd_row_extra* __restrict__ row_extras,
+                                                 const int* __restrict__ row_extra_count, int row_cap,
+                                                 int accumulate, uint16_t* __restrict__ S, int W, int H, int Dp)
+{
+    const int per_row = W * (Dp >> 3);
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= per_row) return;
+    const int row = blockIdx.y;
+    const int x = t / (Dp >> 3);
+    const int chunk = t - x * (Dp >> 3);
+    const size_t off = ((size_t)row * W + x) * Dp + chunk * 8;
+
+    unsigned acc[8];
+    if (accumulate) {                                    // Q14: S was not reset since the last frame
+        const uint4 s = *reinterpret_cast<const uint4*>(S + off);
+        acc[0] = s.x & 0xFFFF; acc[1] = s.x >> 16; acc[2] = s.y & 0xFFFF; acc[3] = s.y >> 16;
+        acc[4] = s.z & 0xFFFF; acc[5] = s.z >> 16; acc[6] = s.w & 0xFFFF; acc[7] = s.w >> 16;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0;
+    }
+    auto add8 = [&](const uint8_t* p) {
+        const uint2 v = *reinterpret_cast<const uint2*>(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[i] += (v.x >> (8 * i)) & 0xFF;
+            acc[4 + i] += (v.y >> (8 * i)) & 0xFF;
+        }
+    };
+    for (int d = 0; d < ndirs; ++d) add8(planes + (size_t)d * plane_bytes + off);
+    if (ndirs > 4) {
+        const int n = row_extra_count[row];
+        for (int j = 0; j < n; ++j) {
+            const sgmd_row_extra e = row_extras[row * row_cap + j];
+            if ((e.col_slot & 0xFFFF) == x)
+                add8(extras + ((size_t)(e.col_slot >> 16) * H + e.step) * Dp + chunk * 8);
+        }
+    }
+    uint4 o;
+    o.x = (acc[0] & 0xFFFF) | (acc[1] << 16);
+    o.y = (acc[2] & 0xFFFF) | (acc[3] << 16);
+    o.z = (acc[4] & 0xFFFF) | (acc[5] << 16);
+    o.w = (acc[6] & 0xFFFF) | (acc[7] << 16);
+    *reinterpret_cast<uint4*>(S + off) = o;
+}
+
+// ============================================================================================
+// winner-take-all, left and right view  (ref :374-443)
+//
+// One lane = one pixel; a workgroup handles WTA_T consecutive pixels of a row and walks the
+// disparity range in chunks of WTA_DC, staging S through LDS so both the left view (S[x][d])
+// and the right view (S[x+d][d], ref :397-408) read conflict-free LDS instead of strided HBM.
+// ============================================================================================
+
+#define WTA_T 128
+#define WTA_DC 64
+#define WTA_LD (WTA_DC + 2)       // u16 row stride (33 dwords: odd, conflict-free lane stride)
+
+struct WtaState {
+    unsigned m1, m2;   // smallest cost (lowest d wins ties, ref :390) and smallest among the others (ref :413-419)
+    int d1;            // index (d - dmin) of m1, -1 if nothing beat 65535
+    unsigned c1, c2;   // cost_local[best-1], cost_local[best+1] (ref :432-435)
+    unsigned pv;       // cost of the previous index
+    bool want_next;
+};
+
+static __device__ __forceinline__ void wta_feed(WtaState& s, unsigned v, int di)
+{
+    if (s.want_next) { s.c2 = v; s.want_next = false; }
+    if (v < s.m1) {
+        s.m2 = s.m1; s.m1 = v; s.d1 = di; s.c1 = s.pv; s.want_next = true; s.c2 = 0xFFFFu;
+    } else if (v < s.m2) {
+        s.m2 = v;
+    }
+    s.pv = v;
+}
+
+static __device__ __forceinline__ float wta_finish(const WtaState& s, int D, int dmin, int check_unique,
+                                                   float one_minus_ratio)
+{
+    const float inf = __builtin_inff();
+    if (s.d1 < 0) return inf;                             // no candidate at all (see oracle/sgm_oracle.c sgmo_wta)
+    if (check_unique) {                                   // ref :412-426 (Q10)
+        const unsigned margin = (unsigned)(unsigned short)(int)((float)s.m1 * one_minus_ratio);
+        if ((int)s.m2 - (int)s.m1 <= (int)margin) return inf;
+    }
+    if (s.d1 == 0 || s.d1 == D - 1) return inf;          // ref :428
+    const int c1 = (int)(short)s.c1, c2 = (int)(short)s.c2;       // (int16_t) casts, 65535 -> -1 (Q11b)
+    int denom = (int)(short)(c1 + c2 - 2 * (int)s.m1);
+    if (denom < 1) denom = 1;
+    return (float)(s.d1 + dmin) + (float)(c1 - c2) / ((float)denom * 2.0f);     // ref :440
+}
+
+__global__ __launch_bounds__(WTA_T) void sgm_wta_k(const uint16_t* __restrict__ S, float* __restrict__ disp_l,
+                                                   float* __restrict__ disp_r, int W, int H, int D, int Dp, int dmin,
+                                                   int check_unique, float one_minus_ratio, int want_right)
+{
+    __shared__ unsigned short tl[WTA_T * WTA_LD];
+    __shared__ unsigned short tr[(WTA_T + WTA_DC) * WTA_LD];
+    const int row = blockIdx.y;
+    const int x0 = blockIdx.x * WTA_T;
+    const int i = threadIdx.x;
+    const int x = x0 + i;
+    const uint16_t* Srow = S + (size_t)row * W * Dp;
+
+    WtaState sl, sr;
+    sl.m1 = sl.m2 = 0xFFFFu; sl.d1 = -1; sl.c1 = sl.c2 = 0xFFFFu; sl.pv = 0xFFFFu; sl.want_next = false;
+    sr = sl;
+
+    for (int dc = 0; dc < D; dc += WTA_DC) {
+        const int nd = min(WTA_DC, D - dc);
+        __syncthreads();                                  // previous chunk fully consumed
+        // left tile: pixels x0..x0+T-1, disparities dc..dc+DC-1 (8-element = 16-byte pieces)
+        for (int t = i; t < WTA_T * (WTA_DC / 8); t += WTA_T) {
+            const int px = t / (WTA_DC / 8), piece = t % (WTA_DC / 8);
+            const int xx = x0 + px;
+            uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            if (xx < W && dc + piece * 8 < Dp) v = *reinterpret_cast<const uint4*>(Srow + (size_t)xx * Dp + dc + piece * 8);
+            unsigned* dst = reinterpret_cast<unsigned*>(&tl[px * WTA_LD + piece * 8]);
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+        if (want_right) {
+            // right tile: columns x0+dmin+dc .. +T+DC-2; off-image columns read 65535 (ref :407)
+            for (int t = i; t < (WTA_T + WTA_DC) * (WTA_DC / 8); t += WTA_T) {
+                const int px = t / (WTA_DC / 8), piece = t % (WTA_DC / 8);
+                const int xx = x0 + dmin + dc + px;
+                uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                if (xx < W && dc + piece * 8 < Dp) v = *reinterpret_cast<const uint4*>(Srow + (size_t)xx * Dp + dc + piece * 8);
+                unsigned* dst = reinterpret_cast<unsigned*>(&tr[px * WTA_LD + piece * 8]);
+                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            }
+        }
+        __syncthreads();
+        for (int e = 0; e < nd; ++e) {
+            wta_feed(sl, tl[i * WTA_LD + e], dc + e);
+            if (want_right) wta_feed(sr, tr[(i + e) * WTA_LD + e], dc + e);
+        }
+    }
+    if (x < W) {
+        disp_l[(size_t)row * W + x] = wta_finish(sl, D, dmin, check_unique, one_minus_ratio);
+        if (want_right) disp_r[(size_t)row * W + x] = wta_finish(sr, D, dmin, check_unique, one_minus_ratio);
+    }
+}
+
+// ============================================================================================
+// left-right consistency  (ref :445-470)
+// ============================================================================================
+
+__global__ __launch_bounds__(256) void sgm_lrcheck_k(float* __restrict__ dl, const float* __restrict__ dr, int W, int H,
+                                                     float thres)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W) return;
+    const float inf = __builtin_inff();
+    const size_t idx = (size_t)y * W + x;
+    const float d = dl[idx];
+    if (d == inf) return;
+    const int xr = (int)((double)((float)x - d) + 0.5);          // ref :454: float subtract, double add, truncate (Q12)
+    if (xr >= 0 && xr < W) {
+        const float r = dr[(size_t)y * W + xr];
+        if (r == inf) return;                                    // left kept
+        if (fabs((double)(d - r)) > (double)thres) dl[idx] = inf;
+    } else {
+        dl[idx] = inf;
+    }
+}
+
+// ============================================================================================
+// speckle removal  (ref :585-642): union-find connected-component labelling.  The reference's
+// breadth-first flood defines components of the symmetric relation "8-neighbours, both valid,
+// |delta| <= diff", so the result does not depend on traversal order.
+// ============================================================================================
+
+static __device__ __forceinline__ int uf_find(const int* lab, int x)
+{
+    int p = __hip_atomic_load(lab + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != x) { x = p; p = __hip_atomic_load(lab + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    return x;
+}
+static __device__ __forceinline__ void uf_union(int* lab, int a, int b)
+{
+    for (;;) {
+        a = uf_find(lab, a);
+        b = uf_find(lab, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }            // hook the larger root under the smaller
+        const int old = atomicMin(lab + a, b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+__global__ __launch_bounds__(256) void sgm_speckle_init_k(const float* __restrict__ disp, int* __restrict__ lab,
+                                                          int* __restrict__ sizes, int n)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    lab[p] = (disp[p] == __builtin_inff()) ? -1 : p;
+    sizes[p] = 0;
+}
+
+__global__ __launch_bounds__(256) void sgm_speckle_merge_k(const float* __restrict__ disp, int* __restrict__ lab, int W,
+                                                           int H, float diff)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W) return;
+    const int p = y * W + x;
+    const float inf = __builtin_inff();
+    const float v = disp[p];
+    if (v == inf) return;
+    // the four already-scanned neighbours cover every 8-neighbour edge once
+    const int ox[4] = {-1, 0, 1, -1}, oy[4] = {-1, -1, -1, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int xx = x + ox[k], yy = y + oy[k];
+        if (xx < 0 || xx >= W || yy < 0) continue;
+        const int q = yy * W + xx;
+        const float u = disp[q];
+        if (u != inf && fabs((double)(u - v)) <= (double)diff) uf_union(lab, p, q);    // ref :622-624
+    }
+}
+
+__global__ __launch_bounds__(256) void sgm_speckle_count_k(int* __restrict__ lab, int* __restrict__ sizes, int n)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    if (lab[p] < 0) return;
+    const int r = uf_find(lab, p);
+    atomicAdd(sizes + r, 1);
+}
+
+__global__ __launch_bounds__(256) void sgm_speckle_apply_k(float* __restrict__ disp, const int* __restrict__ lab,
+                                                           const int* __restrict__ sizes, int n, unsigned min_area)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    if (lab[p] < 0) return;
+    const int r = uf_find(lab, p);
+    if ((unsigned)sizes[r] < min_area) disp[p] = __builtin_inff();           // ref :633
+}
+
+// ============================================================================================
+// in-place 3x3 median  (ref :525-557 with in == out, .c:120 -> raster-order recurrence, Q13)
+//
+// Output (y,x) sees filtered values at (y-1,x-1..x+1) and (y,x-1), originals elsewhere.  One
+// thread per image row, skewed by two columns per row, walks the rows as a wavefront: at step t
+// thread r is at column t - 2r + 1, so everything it needs from row y-1 was produced at least
+// one step earlier.  Filtered values travel to the row below through a 4-column LDS ring.
+// ============================================================================================
+
+static __device__ __forceinline__ void cswap(float& a, float& b)
+{
+    const float lo = fminf(a, b), hi = fmaxf(a, b);
+    a = lo; b = hi;
+}
+// 5th smallest of 9 (ref :496-523); +INF orders last, NaN never occurs (Q15)
+static __device__ __forceinline__ float median9(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
+                                                float v7, float v8)
+{
+    cswap(v1, v2); cswap(v4, v5); cswap(v7, v8);
+    cswap(v0, v1); cswap(v3, v4); cswap(v6, v7);
+    cswap(v1, v2); cswap(v4, v5); cswap(v7, v8);
+    cswap(v0, v3); cswap(v5, v8); cswap(v4, v7);
+    cswap(v3, v6); cswap(v1, v4); cswap(v2, v5);
+    cswap(v4, v7); cswap(v4, v2); cswap(v6, v4);
+    cswap(v4, v2);
+    return v4;
+}
+
+#define MED_THREADS 1024
+#define MED_PF 8
+
+__global__ __launch_bounds__(MED_THREADS) void sgm_median_k(float* __restrict__ disp, int W, int H)
+{
+    __shared__ float ring[MED_THREADS][4];
+    const int r = threadIdx.x;
+    const int rows = H - 2;                                        // interior rows 1..H-2
+    if (rows <= 0 || W <= 2) return;
+    for (int band = 0; band * MED_THREADS < rows; ++band) {
+        const int y = 1 + band * MED_THREADS + r;
+        const bool have_row = (y <= H - 2);
+        const int band_rows = min(MED_THREADS, rows - band * MED_THREADS);
+        const int nsteps = (W - 2) + 2 * (band_rows - 1);
+        const float* own = disp + (size_t)(have_row ? y : 1) * W;
+        const float* below = own + W;
+        const float* above = own - W;                              // read from memory only by thread 0 of the band
+        float left = own[0];                                       // in(y,0): border, never modified
+        float cur = own[1];
+        float b0 = below[0], b1 = below[1];
+        // originals of columns x+1 for the coming steps (own row and the row below)
+        float po[MED_PF], pbw[MED_PF];
+#pragma unroll
+        for (int u = 0; u < MED_PF; ++u) {
+            const int c = 2 + u;
+            po[u] = (c < W) ? own[c] : 0.f;
+            pbw[u] = (c < W) ? below[c] : 0.f;
+        }
+        __syncthreads();
+        for (int t0 = 0; t0 < nsteps; t0 += MED_PF) {
+#pragma unroll
+            for (int u = 0; u < MED_PF; ++u) {
+                const int t = t0 + u;
+                if (t < nsteps) {                                  // uniform
+                    const int x = t - 2 * r + 1;
+                    const bool on = have_row && x >= 1 && x <= W - 2;
+                    float outv = 0.f;
+                    if (on) {
+                        const float nxt = po[u], b2 = pbw[u];      // in(y,x+1), in(y+1,x+1)
+                        float a0, a1, a2;
+                        if (r == 0) {
+                            // row above the band: image border row or the finished last row of the previous band
+                            a0 = __hip_atomic_load(above + x - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            a1 = __hip_atomic_load(above + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            a2 = __hip_atomic_load(above + x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } else {
+                            // filtered interior columns come from the ring; columns 0 and W-1 are border originals
+                            a0 = (x - 1 >= 1) ? ring[r - 1][(x - 1) & 3] : above[0];
+                            a1 = ring[r - 1][x & 3];
+                            a2 = (x + 1 <= W - 2) ? ring[r - 1][(x + 1) & 3] : above[W - 1];
+                        }
+                        outv = median9(a0, a1, a2, left, cur, nxt, b0, b1, b2);
+                        left = outv; cur = nxt; b0 = b1; b1 = b2;
+                        // refill the prefetch slot with column x + 1 + MED_PF
+                        const int c = x + 1 + MED_PF;
+                        po[u] = (c < W) ? own[c] : 0.f;
+                        pbw[u] = (c < W) ? below[c] : 0.f;
+                    }
+                    if (on) {
+                        ring[r][x & 3] = outv;
+                        disp[(size_t)y * W + x] = outv;
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ============================================================================================
+// host-callable launchers
+// ============================================================================================
+
+template <int DPL>
+static void launch_aggregate(const AggArgs& a, int blocks, bool pad, hipStream_t st)
+{
+    if (pad) hipLaunchKernelGGL((sgm_aggregate_k<DPL, true>), dim3(blocks), dim3(64), 0, st, a);
+    else     hipLaunchKernelGGL((sgm_aggregate_k<DPL, false>), dim3(blocks), dim3(64), 0, st, a);
+}
+
+extern "C" {
+
+int sgmd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sgmd_device_is_gfx950(int ordinal)
+{
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ordinal) != hipSuccess) return -1;
+    return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+int sgmd_stream_create(int ord, void** stream)
+{
+    HIP_TRY(hipSetDevice(ord));
+    hipStream_t s;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void*)s;
+    return 0;
+}
+int sgmd_stream_destroy(int ord, void* stream)
+{
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}
+int sgmd_stream_sync(int ord, void* stream)
+{
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+int sgmd_alloc(int ord, void** dptr, size_t bytes)
+{
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 16));
+    return 0;
+}
+int sgmd_free(int ord, void* dptr)
+{
+    if (!dptr) return 0;
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipFree(dptr));
+    return 0;
+}
+int sgmd_alloc_pinned(int ord, void** hptr, size_t bytes)
+{
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipHostMalloc(hptr, bytes ? bytes : 16, hipHostMallocDefault));
+    return 0;
+}
+int sgmd_free_pinned(int ord, void* hptr)
+{
+    if (!hptr) return 0;
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipHostFree(hptr));
+    return 0;
+}
+int sgmd_h2d_async(int ord, void* stream, void* dst, const void* src, size_t bytes)
+{
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return 0;
+}
+int sgmd_d2h_async(int ord, void* stream, void* dst, const void* src, size_t bytes)
+{
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return 0;
+}
+int sgmd_d2d_async(int ord, void* stream, void* dst, const void* src, size_t bytes)
+{
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+int sgmd_memset_async(int ord, void* stream, void* dst, int value, size_t bytes)
+{
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
+    return 0;
+}
+
+struct sgmd_timer { int n; hipEvent_t* ev; };
+
+int sgmd_timer_create(int ord, void** timer, int max_marks)
+{
+    HIP_TRY(hipSetDevice(ord));
+    sgmd_timer* t = new sgmd_timer;
+    t->n = max_marks;
+    t->ev = new hipEvent_t[max_marks];
+    for (int i = 0; i < max_marks; ++i) HIP_TRY(hipEventCreate(&t->ev[i]));
+    *timer = t;
+    return 0;
+}
+void sgmd_timer_destroy(int ord, void* timer)
+{
+    if (!timer) return;
+    (void)hipSetDevice(ord);
+    sgmd_timer* t = (sgmd_timer*)timer;
+    for (int i = 0; i < t->n; ++i) (void)hipEventDestroy(t->ev[i]);
+    delete[] t->ev;
+    delete t;
+}
+int sgmd_timer_mark(int ord, void* timer, void* stream, int index)
+{
+    sgmd_timer* t = (sgmd_timer*)timer;
+    if (!t || index < 0 || index >= t->n) return -1;
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipEventRecord(t->ev[index], (hipStream_t)stream));
+    return 0;
+}
+int sgmd_timer_elapsed(int ord, void* timer, int from, int to, float* ms)
+{
+    sgmd_timer* t = (sgmd_timer*)timer;
+    if (!t) return -1;
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipEventElapsedTime(ms, t->ev[from], t->ev[to]));
+    return 0;
+}
+
+int sgmd_census(int ord, void* stream, const sgmd_geom* g, const void* left, const void* right, void* cl, void* cr)
+{
+    HIP_TRY(hipSetDevice(ord));
+    dim3 grid((g->W + 63) / 64, (g->H + 3) / 4, 2);
+    hipLaunchKernelGGL(sgm_census_k, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)left,
+                       (const uint8_t*)right, (uint32_t*)cl, (uint32_t*)cr, g->W, g->H);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sgmd_cost(int ord, void* stream, const sgmd_geom* g, const void* cl, const void* cr, void* cost)
+{
+    HIP_TRY(hipSetDevice(ord));
+    const long long total = (long long)g->W * g->H * (g->Dp / 16);
+    dim3 grid((unsigned)((total + 255) / 256));
+    hipLaunchKernelGGL(sgm_cost_k, grid, dim3(256), 0, (hipStream_t)stream, (const uint32_t*)cl, (const uint32_t*)cr,
+                       (uint8_t*)cost, g->W, g->H, g->D, g->Dp, g->dmin);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sgmd_aggregate(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* paths, const void* img_left,
+                   const void* cost, const void* lut, void* planes, size_t plane_bytes, void* extras)
+{
+    HIP_TRY(hipSetDevice(ord));
+    AggArgs a;
+    a.img = (const uint8_t*)img_left;
+    a.cost = (const uint8_t*)cost;
+    a.lut = (const uint16_t*)lut;
+    a.planes = (uint8_t*)planes;
+    a.plane_bytes = plane_bytes;
+    a.extras = (uint8_t*)extras;
+    a.W = g->W; a.H = g->H; a.D = g->D; a.Dp = g->Dp;
+    a.p1 = paths->p1;
+    a.ndirs = paths->ndirs;
+    a.ghost_zero = paths->ghost_zero;
+    int blocks = 0;
+    for (int d = 0; d < 8; ++d) {
+        a.dx[d] = paths->dx[d]; a.dy[d] = paths->dy[d]; a.anom_line[d] = paths->anom_line[d];
+        a.block_begin[d] = blocks;
+        if (d < paths->ndirs) {
+            const int nlines = (paths->dy[d] == 0) ? g->H : g->W;
+            blocks += (nlines + 3) / 4;
+        }
+    }
+    a.block_begin[8] = blocks;
+    const bool pad = (g->D != g->Dp);
+    hipStream_t st = (hipStream_t)stream;
+    switch (g->DPL) {
+    case 2:  launch_aggregate<2>(a, blocks, pad, st); break;
+    case 4:  launch_aggregate<4>(a, blocks, pad, st); break;
+    case 8:  launch_aggregate<8>(a, blocks, pad, st); break;
+    case 12: launch_aggregate<12>(a, blocks, pad, st); break;
+    case 16: launch_aggregate<16>(a, blocks, pad, st); break;
+    case 32: launch_aggregate<32>(a, blocks, pad, st); break;
+    default:
+        fprintf(stderr, "sgm_mi355x: unsupported DPL %d\n", g->DPL);
+        return -1;
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sgmd_sum(int ord, void* stream, const sgmd_geom* g, int ndirs, const void* planes, size_t plane_bytes,
+             const void* extras, const void* row_extras, const void* row_extra_count, int row_cap, int accumulate,
+             void* S)
+{
+    HIP_TRY(hipSetDevice(ord));
+    const int per_row = g->W * (g->Dp / 8);
+    dim3 grid((per_row + 255) / 256, g->H);
+    hipLaunchKernelGGL(sgm_sum_k, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)planes, plane_bytes, ndirs,
+                       (const uint8_t*)extras, (const sgmd_row_extra*)row_extras, (const int*)row_extra_count, row_cap,
+                       accumulate, (uint16_t*)S, g->W, g->H, g->Dp);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sgmd_wta(int ord, void* stream, const sgmd_geom* g, const void* S, int check_unique, float one_minus_ratio,
+             int want_right, void* disp_l, void* disp_r)
+{
+    HIP_TRY(hipSetDevice(ord));
+    dim3 grid((g->W + WTA_T - 1) / WTA_T, g->H);
+    hipLaunchKernelGGL(sgm_wta_k, grid, dim3(WTA_T), 0, (hipStream_t)stream, (const uint16_t*)S, (float*)disp_l,
+                       (float*)disp_r, g->W, g->H, g->D, g->Dp, g->dmin, check_unique, one_minus_ratio, want_right);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sgmd_lrcheck(int ord, void* stream, const sgmd_geom* g, void* disp_l, const void* disp_r, float thres)
+{
+    HIP_TRY(hipSetDevice(ord));
+    dim3 grid((g->W + 255) / 256, g->H);
+    hipLaunchKernelGGL(sgm_lrcheck_k, grid, dim3(256), 0, (hipStream_t)stream, (float*)disp_l, (const float*)disp_r,
+                       g->W, g->H, thres);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sgmd_speckle(int ord, void* stream, const sgmd_geom* g, void* disp, float diff, unsigned min_area, void* labels,
+                 void* sizes)
+{
+    HIP_TRY(hipSetDevice(ord));
+    hipStream_t st = (hipStream_t)stream;
+    const int n = g->W * g->H;
+    const dim3 lin((n + 255) / 256), b(256);
+    hipLaunchKernelGGL(sgm_speckle_init_k, lin, b, 0, st, (const float*)disp, (int*)labels, (int*)sizes, n);
+    hipLaunchKernelGGL(sgm_speckle_merge_k, dim3((g->W + 255) / 256, g->H), b, 0, st, (const float*)disp, (int*)labels,
+                       g->W, g->H, diff);
+    hipLaunchKernelGGL(sgm_speckle_count_k, lin, b, 0, st, (int*)labels, (int*)sizes, n);
+    hipLaunchKernelGGL(sgm_speckle_apply_k, lin, b, 0, st, (float*)disp, (const int*)labels, (const int*)sizes, n,
+                       min_area);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sgmd_median(int ord, void* stream, const sgmd_geom* g, void* disp)
+{
+    HIP_TRY(hipSetDevice(ord));
+    hipLaunchKernelGGL(sgm_median_k, dim3(1), dim3(MED_THREADS), 0, (hipStream_t)stream, (float*)disp, g->W, g->H);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

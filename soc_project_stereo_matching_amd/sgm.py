@@ -1,0 +1,276 @@
+"""ctypes mirror of include/sgm_mi355x.h.
+
+``SGM`` wraps the reference-shaped global entry points (SGM_Initialize / SGM_Reset / SGM_Match,
+reference SemiGlobalMatching.h:78-80); ``SGMInstance`` wraps the explicit-instance extension
+(several frames in flight, device-resident buffers).  Names, argument meaning and the
+True/False error behaviour follow the C interface one to one.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+STAGE_NAMES = ["census_l", "census_r", "cost", "aggr", "disp_l", "disp_r", "after_lr", "after_speckle", "final"]
+_STAGE_DTYPE = [np.uint32, np.uint32, np.uint8, np.uint16] + [np.float32] * 5
+
+
+class SGMOption(C.Structure):
+    """Field-for-field the reference's SGMOption (SemiGlobalMatching.h:24-40), 28 bytes."""
+    _fields_ = [
+        ("num_paths", C.c_uint8),
+        ("min_disparity", C.c_uint16),
+        ("max_disparity", C.c_uint16),
+        ("is_check_unique", C.c_bool),
+        ("uniqueness_ratio", C.c_float),
+        ("is_check_lr", C.c_bool),
+        ("lrcheck_thres", C.c_float),
+        ("is_remove_speckles", C.c_bool),
+        ("min_speckle_area", C.c_uint16),
+        ("p1", C.c_int16),
+        ("p2_init", C.c_int16),
+    ]
+
+
+def default_option(max_disparity=64, min_disparity=0, **kw) -> SGMOption:
+    """The option values the reference's driver sets (main.c:48-65), with overrides."""
+    o = SGMOption()
+    o.num_paths = 8
+    o.min_disparity = min_disparity
+    o.max_disparity = max_disparity
+    o.is_check_lr = True
+    o.lrcheck_thres = 1.0
+    o.is_check_unique = True
+    o.uniqueness_ratio = 0.99
+    o.is_remove_speckles = True
+    o.min_speckle_area = 50
+    o.p1 = 10
+    o.p2_init = 150
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def library_path() -> str:
+    return os.path.join(_HERE, "libsgm_mi355x.so")
+
+
+def load_library() -> C.CDLL:
+    """Load libsgm_mi355x.so (built by csrc/Makefile or __graft_entry__.build()).  There is no
+    fallback: a missing library is an error."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: build it with `make -C soc_project_stereo_matching_amd/csrc` "
+                           "(needs hipcc); there is no CPU fallback")
+    L = C.CDLL(path)
+    opt_p = C.POINTER(SGMOption)
+    for f in (L.SGM_Initialize, L.SGM_Reset):
+        f.argtypes = [C.c_uint16, C.c_uint16, opt_p]
+        f.restype = C.c_bool
+    for f in (L.SGM_Match, L.SGM_MatchDevice):
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        f.restype = C.c_bool
+    L.SGM_Synchronize.restype = C.c_bool
+    L.SGM_SetDevice.argtypes = [C.c_int]
+    L.SGM_SetDevice.restype = C.c_bool
+    L.SGM_SetHonorNumPaths.argtypes = [C.c_int]
+    L.SGM_KeepStages.argtypes = [C.c_int]
+    L.SGM_ReadStage.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
+    L.SGM_ReadStage.restype = C.c_size_t
+    L.SGM_SynthPair.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.SGM_Version.restype = C.c_char_p
+    L.sgm_create.argtypes = [C.c_int]
+    L.sgm_create.restype = C.c_void_p
+    L.sgm_destroy.argtypes = [C.c_void_p]
+    L.sgm_set_honor_num_paths.argtypes = [C.c_void_p, C.c_int]
+    L.sgm_keep_stages.argtypes = [C.c_void_p, C.c_int]
+    for f in (L.sgm_initialize, L.sgm_reset):
+        f.argtypes = [C.c_void_p, C.c_uint16, C.c_uint16, opt_p]
+        f.restype = C.c_bool
+    for f in (L.sgm_match, L.sgm_match_device):
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        f.restype = C.c_bool
+    L.sgm_synchronize.argtypes = [C.c_void_p]
+    L.sgm_synchronize.restype = C.c_bool
+    L.sgm_stream.argtypes = [C.c_void_p]
+    L.sgm_stream.restype = C.c_void_p
+    L.sgm_read_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.sgm_read_stage.restype = C.c_size_t
+    L.sgm_enable_timing.argtypes = [C.c_void_p, C.c_int]
+    L.sgm_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
+    L.sgm_last_timing.restype = C.c_int
+    L.sgm_host_walk_line.argtypes = [C.c_int] * 5 + [C.c_void_p]
+    L.sgm_host_walk_line.restype = C.c_int
+    L.sgm_host_anomalous_line.argtypes = [C.c_int, C.c_int]
+    L.sgm_host_anomalous_line.restype = C.c_int
+    L.sgm_host_p2_table.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    _LIB = L
+    return L
+
+
+def synth_pair(width, height, disparity_range, seed):
+    """Seeded synthetic stereo pair from the library's own host generator."""
+    L = load_library()
+    left = np.empty((height, width), np.uint8)
+    right = np.empty((height, width), np.uint8)
+    L.SGM_SynthPair(width, height, disparity_range, seed & 0xFFFFFFFF, left.ctypes.data, right.ctypes.data)
+    return left, right
+
+
+def _u8(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype != np.uint8:
+        raise TypeError("images must be uint8")
+    return a
+
+
+class _StageReader:
+    def _read(self, which):
+        raise NotImplementedError
+
+    def read_stage(self, which):
+        """Copy one intermediate buffer of the last match to the host (parity tests)."""
+        idx = STAGE_NAMES.index(which) if isinstance(which, str) else which
+        h, w, d = self.shape
+        if idx >= 10:
+            dt, shp = np.uint8, (h, w, d)
+        else:
+            dt, shp = _STAGE_DTYPE[idx], ((h, w, d) if idx in (2, 3) else (h, w))
+        out = np.empty(shp, dt)
+        got = self._read(idx, out)
+        if got != out.nbytes:
+            raise RuntimeError(f"read_stage({which}) returned {got} of {out.nbytes} bytes")
+        return out
+
+    def read_stages(self):
+        return {n: self.read_stage(n) for n in STAGE_NAMES}
+
+
+class SGM(_StageReader):
+    """The reference's global-instance API: SGM_Initialize / SGM_Reset / SGM_Match."""
+
+    def __init__(self):
+        self.lib = load_library()
+        self.shape = None
+
+    def set_device(self, ordinal) -> bool:
+        return bool(self.lib.SGM_SetDevice(ordinal))
+
+    def set_honor_num_paths(self, honor):
+        self.lib.SGM_SetHonorNumPaths(int(honor))
+
+    def keep_stages(self, enable=True):
+        self.lib.SGM_KeepStages(int(enable))
+
+    def initialize(self, width, height, option) -> bool:
+        ok = bool(self.lib.SGM_Initialize(width, height, C.byref(option)))
+        if ok:
+            self.shape = (height, width, option.max_disparity - option.min_disparity)
+        return ok
+
+    def reset(self, width, height, option) -> bool:
+        ok = bool(self.lib.SGM_Reset(width, height, C.byref(option)))
+        if ok:
+            self.shape = (height, width, option.max_disparity - option.min_disparity)
+        return ok
+
+    def match(self, left, right):
+        """Returns the float32 disparity map, or None where the C call returns false."""
+        if left is None or right is None:
+            assert not self.lib.SGM_Match(None, None, None)
+            return None
+        left, right = _u8(left), _u8(right)
+        out = np.empty(left.shape, np.float32)
+        ok = self.lib.SGM_Match(left.ctypes.data, right.ctypes.data, out.ctypes.data)
+        return out if ok else None
+
+    def match_device(self, d_left: int, d_right: int, d_out: int) -> bool:
+        return bool(self.lib.SGM_MatchDevice(d_left, d_right, d_out))
+
+    def synchronize(self) -> bool:
+        return bool(self.lib.SGM_Synchronize())
+
+    def shutdown(self):
+        self.lib.SGM_Shutdown()
+
+    def _read(self, idx, out):
+        return self.lib.SGM_ReadStage(idx, out.ctypes.data, out.nbytes)
+
+
+class SGMInstance(_StageReader):
+    """Explicit instance (extension): own HIP stream and buffers on one GPU."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.handle = self.lib.sgm_create(device)
+        if not self.handle:
+            raise RuntimeError(f"sgm_create({device}) failed: no usable gfx950 device (no CPU fallback)")
+        self.device = device
+        self.shape = None
+
+    def close(self):
+        if self.handle:
+            self.lib.sgm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_honor_num_paths(self, honor):
+        self.lib.sgm_set_honor_num_paths(self.handle, int(honor))
+
+    def keep_stages(self, enable=True):
+        self.lib.sgm_keep_stages(self.handle, int(enable))
+
+    def enable_timing(self, enable=True):
+        self.lib.sgm_enable_timing(self.handle, int(enable))
+
+    def last_timing(self):
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        n = self.lib.sgm_last_timing(self.handle, names, ms, 16)
+        return {names[i].decode(): float(ms[i]) for i in range(n)}
+
+    def initialize(self, width, height, option) -> bool:
+        ok = bool(self.lib.sgm_initialize(self.handle, width, height, C.byref(option)))
+        if ok:
+            self.shape = (height, width, option.max_disparity - option.min_disparity)
+        return ok
+
+    def reset(self, width, height, option) -> bool:
+        ok = bool(self.lib.sgm_reset(self.handle, width, height, C.byref(option)))
+        if ok:
+            self.shape = (height, width, option.max_disparity - option.min_disparity)
+        return ok
+
+    def match(self, left, right):
+        left, right = _u8(left), _u8(right)
+        out = np.empty(left.shape, np.float32)
+        ok = self.lib.sgm_match(self.handle, left.ctypes.data, right.ctypes.data, out.ctypes.data)
+        return out if ok else None
+
+    def match_device(self, d_left: int, d_right: int, d_out: int) -> bool:
+        """Device pointers (e.g. torch tensor .data_ptr()); asynchronous on the instance stream."""
+        return bool(self.lib.sgm_match_device(self.handle, d_left, d_right, d_out))
+
+    def synchronize(self) -> bool:
+        return bool(self.lib.sgm_synchronize(self.handle))
+
+    @property
+    def stream(self) -> int:
+        return self.lib.sgm_stream(self.handle) or 0
+
+    def _read(self, idx, out):
+        return self.lib.sgm_read_stage(self.handle, idx, out.ctypes.data, out.nbytes)
