@@ -726,9 +726,11 @@ __global__ __launch_bounds__(MED_THREADS) void sgm_median_k(float* __restrict__ 
         float b0 = below[0], b1 = below[1];
         // originals of columns x+1 for the coming steps (own row and the row below)
         float po[MED_PF], pbw[MED_PF];
+        // ring slot u is consumed at steps t == u (mod MED_PF); thread r starts at t = 2r, so its ring
+        // is rotated by 2r: slot u initially holds column 2 + ((u - 2r) mod MED_PF)
 #pragma unroll
         for (int u = 0; u < MED_PF; ++u) {
-            const int c = 2 + u;
+            const int c = 2 + ((u - 2 * r) & (MED_PF - 1));
             po[u] = (c < W) ? own[c] : 0.f;
             pbw[u] = (c < W) ? below[c] : 0.f;
         }
@@ -766,7 +768,9 @@ __global__ __launch_bounds__(MED_THREADS) void sgm_median_k(float* __restrict__ 
                         ring[r][x & 3] = outv;
                         disp[(size_t)y * W + x] = outv;
                     }
-                    __syncthreads();
+                    // rows talk through the LDS ring only: wait for the LDS write, not for the global
+                    // prefetch loads / result stores still in flight (a __syncthreads() would drain them)
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 }
             }
         }

@@ -72,7 +72,7 @@ def load_library() -> C.CDLL:
         raise RuntimeError(f"{path} is missing: build it with `make -C soc_project_stereo_matching_amd/csrc` "
                            "(needs hipcc); there is no CPU fallback")
     L = C.CDLL(path)
-    opt_p = C.POINTER(SGMOption)
+    opt_p = C.c_void_p      # any ctypes structure with the SGMOption layout (28 bytes)
     for f in (L.SGM_Initialize, L.SGM_Reset):
         f.argtypes = [C.c_uint16, C.c_uint16, opt_p]
         f.restype = C.c_bool

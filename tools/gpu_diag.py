@@ -90,6 +90,7 @@ def main():
         (300, 60, 0, 128, 9, {}),
         (300, 60, 0, 192, 10, {}),
         (400, 48, 0, 256, 11, {"min_speckle_area": 20}),
+        (40, 1100, 0, 8, 14, {"min_speckle_area": 6}),
         (450, 375, 0, 64, 12, {}),
         (1242, 375, 0, 128, 13, {}),
     ]
