@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the SGM hot path on MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE frame through the reference's entry points, SGM_Reset + SGM_Match (the Reset is part
+of the frame), here their device-pointer forms sgm_reset + sgm_match_device because
+the frames are already resident in HBM when the timed region starts.  All stages run (census, cost,
+8-path aggregation, WTA, LR check, speckle removal, median = the options of the reference's main.c).
+Frames are independent units, so with N GPUs every rank streams its own K frames (weak scaling,
+no data-path collective); `value` is the whole-job aggregate.
+
+Headline workload = BASELINE.json configs[1]: KITTI 1242x375, D=128, 8 paths.
+Metric: Mdisp/s = W*H*D*paths*frames / t / 1e6  (BASELINE.json "metric").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (W, H, D, seed, golden case whose digest pins frame 0)
+    "kitti_1242x375_d128_p8": (1242, 375, 128, 0x5EED0002, "c2_kitti_1242x375_d128"),
+    "cone_450x375_d64_p8": (450, 375, 64, 0x5EED0001, "c1_synth_450x375_d64"),
+    "middlebury_2880x1988_d256_p8": (2880, 1988, 256, 0x5EED0003, None),
+    "drivingstereo_1762x800_d192_p8": (1762, 800, 192, 0x5EED0005, None),
+}
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+PATHS = 8
+
+
+def cpu_baseline(w, h, d, seed, budget_s=25.0):
+    """The reference's C (oracle/_ref, built from /root/reference in the build container) timed on one
+    host core on a bounded sample of the same workload; falls back to our C port of it."""
+    from oracle.pyoracle import Oracle, Reference, default_option
+    import soc_project_stereo_matching_amd as S
+    opt = default_option(d)
+    ref = Reference.for_shape(w, h, d)
+    frames = [S.synth_pair(w, h, d, seed + k) for k in range(2)]
+    if ref is not None:
+        kind, run = "reference", (lambda l, r: ref.api_match(l, r, opt, reset=True))
+    else:
+        orc = Oracle()
+        kind = "port"
+
+        def run(l, r):
+            assert orc.reset(w, h, opt)
+            return orc.match(l, r)
+    times = []
+    t_start = time.perf_counter()
+    k = 0
+    while True:
+        l, r = frames[k % 2]
+        t0 = time.perf_counter()
+        out = run(l, r)
+        times.append(time.perf_counter() - t0)
+        assert out is not None
+        k += 1
+        if k >= 5 or (time.perf_counter() - t_start) + times[-1] > budget_s:
+            break
+    t = float(np.median(times))
+    return {"value": round(w * h * d * PATHS / t / 1e6, 2), "unit": "Mdisp/s", "cores": 1, "kind": kind,
+            "sample": f"{k} frame(s) of {w}x{h} D={d} 8 paths, SGM_Reset+SGM_Match each, median; "
+                      f"{t:.2f} s/frame = {1.0 / t:.3f} fps on 1 of {os.cpu_count()} host cores",
+            "fps": round(1.0 / t, 4)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="kitti_1242x375_d128_p8", choices=sorted(WORKLOADS))
+    ap.add_argument("--in-flight", type=int, default=4, help="instances (HIP streams) a rank round-robins frames over")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import soc_project_stereo_matching_amd as S
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    w, h, d, seed, golden = WORKLOADS[args.workload]
+    opt = S.default_option(d)
+    n_inst = max(1, args.in_flight)
+    insts = [S.SGMInstance(local_rank) for _ in range(n_inst)]
+    for i in insts:
+        if not i.reset(w, h, opt):
+            raise SystemExit("sgm_reset failed")
+        i.enable_timing(True)
+
+    # synthetic frames, resident in HBM before the timed region (4 distinct pairs per rank)
+    n_frames = 4
+    frames = []
+    for k in range(n_frames):
+        l, r = S.synth_pair(w, h, d, seed + k + 16 * rank)
+        frames.append((torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()))
+    outs = [torch.empty((h, w), dtype=torch.float32, device="cuda") for _ in range(n_inst)]
+    torch.cuda.synchronize()
+
+    def step(k):
+        i = insts[k % n_inst]
+        l, r = frames[k % n_frames]
+        if not i.reset(w, h, opt):                       # SGM_Reset: part of every frame (Q14)
+            raise RuntimeError("sgm_reset failed")
+        if not i.match_device(l.data_ptr(), r.data_ptr(), outs[k % n_inst].data_ptr()):
+            raise RuntimeError("sgm_match_device failed")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for k in range(args.warmup):
+        step(k)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    for i in insts:
+        i.synchronize()                                  # collects the HIP-event stage times of each instance's last frame
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel device time of the last frame on each stream of this rank (HIP events on that stream)
+    stage_ms = {}
+    for i in insts[: min(n_inst, args.steps)]:
+        for name, ms in i.last_timing().items():
+            stage_ms.setdefault(name, []).append(ms)
+    stage_ms = {k: float(np.mean(v)) for k, v in stage_ms.items()}
+
+    # single-frame latency (one instance, nothing else in flight), after the timed region
+    lat = []
+    for _ in range(5):
+        insts[0].reset(w, h, opt)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        insts[0].match_device(frames[0][0].data_ptr(), frames[0][1].data_ptr(), outs[0].data_ptr())
+        insts[0].synchronize()
+        lat.append(time.perf_counter() - t1)
+    solo_ms = insts[0].last_timing()
+
+    verified = None
+    if golden is not None and rank == 0:
+        import hashlib
+        with open(os.path.join(ROOT, "tests", "golden", "cases.json")) as f:
+            want = {c["name"]: c for c in json.load(f)["cases"]}[golden]["sha256"]["final"]
+        verified = hashlib.sha256(outs[0].cpu().numpy().tobytes()).hexdigest() == want
+
+    if rank == 0:
+        total_frames = args.steps * world
+        cells = w * h * d
+        value = cells * PATHS * total_frames / elapsed / 1e6
+        ms_per_step = elapsed / args.steps * 1e3
+        # dominant kernel = the one-launch 8-direction aggregation: 5 algorithmic bytes per path
+        # evaluation (read C 1 B + read-modify-write S 2+2 B) x W*H*D*8 per launch
+        agg_ms = stage_ms.get("aggregate")
+        agg_bytes = cells * 5 * PATHS
+        roofline = None
+        if agg_ms:
+            achieved = agg_bytes / (agg_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "sgm_aggregate_k", "achieved": round(achieved, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": None, "avg_launch_ms": round(agg_ms, 4),
+                        "algorithmic_bytes_per_launch": agg_bytes}
+            prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+            if os.path.exists(prof):
+                with open(prof) as f:
+                    roofline["traffic"] = json.load(f).get(args.workload, {}).get("sgm_aggregate_k")
+        frame_bytes = cells * (5 * PATHS + 3)
+        line = {
+            "metric": "Mdisp/s (W*H*D*paths per second), fps beside it",
+            "value": round(value, 1), "unit": "Mdisp/s",
+            "fps": round(total_frames / elapsed, 2),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/u16 integer min-plus (f32 sub-pixel tail)", "data": "synthetic",
+            "config": {"workload": args.workload, "width": w, "height": h, "disparity_range": d, "paths": PATHS,
+                       "stages": "census+cost+aggregate8+wta+lrcheck+speckle+median", "frames_per_gpu": args.steps,
+                       "frames_in_flight_per_gpu": n_inst, "sharding": "independent frames per rank, no collective"},
+            "roofline": roofline,
+            "frame_roofline": {"algorithmic_bytes_per_frame": frame_bytes,
+                               "achieved_GBps_per_gpu": round(frame_bytes * args.steps / elapsed / 1e9, 1),
+                               "frac_per_gpu": round(frame_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
+            "stage_ms_in_flight": {k: round(v, 4) for k, v in stage_ms.items()},
+            "stage_ms_single_frame": {k: round(v, 4) for k, v in solo_ms.items()},
+            "single_frame_latency_ms": round(float(np.median(lat)) * 1e3, 4),
+            "verified_against_golden": verified,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(w, h, d, seed)
+            line["cpu_baseline"] = cb
+            line["speedup_vs_cpu_baseline"] = round(value / cb["value"], 1)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+
+    for i in insts:
+        i.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

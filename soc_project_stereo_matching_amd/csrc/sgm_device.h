@@ -86,12 +86,14 @@ int sgmd_wta(int ord, void* stream, const sgmd_geom* g, const void* S, int check
 int sgmd_lrcheck(int ord, void* stream, const sgmd_geom* g, void* disp_l, const void* disp_r, float thres);
 
 /* connected components (|delta| <= diff, 8-neighbourhood) smaller than min_area -> +INF.
- * labels/sizes: int32 [H][W] scratch.  SemiGlobalMatching.c:585-642 */
+ * labels/sizes/totals: int32 [H][W] scratch each.  SemiGlobalMatching.c:585-642 */
 int sgmd_speckle(int ord, void* stream, const sgmd_geom* g, void* disp, float diff, unsigned min_area,
-                 void* labels, void* sizes);
+                 void* labels, void* sizes, void* totals);
 
-/* in-place raster-order 3x3 median (the reference calls MedianFilter with in == out, .c:120) */
-int sgmd_median(int ord, void* stream, const sgmd_geom* g, void* disp);
+/* in-place raster-order 3x3 median (the reference calls MedianFilter with in == out, .c:120).
+ * scratch: sgmd_median_scratch_bytes(g) bytes for the pre-sorted neighbourhoods. */
+size_t sgmd_median_scratch_bytes(const sgmd_geom* g);
+int sgmd_median(int ord, void* stream, const sgmd_geom* g, void* disp, void* scratch);
 
 #ifdef __cplusplus
 }

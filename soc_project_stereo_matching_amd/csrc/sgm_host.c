@@ -46,12 +46,12 @@ struct sgm_instance {
     bool have_ms;
 
     /* device buffers (capacity tracked so a Reset with the same shape allocates nothing) */
-    size_t cap_px, cap_cells, cap_extras;
+    size_t cap_px, cap_cells, cap_extras, cap_median;
     int cap_H, cap_row_cap;
     int tab_W, tab_H, tab_ndirs, tab_p1, tab_p2;   /* what the uploaded tables were built for */
     void *d_left, *d_right, *d_census_l, *d_census_r, *d_cost, *d_planes, *d_extras, *d_S;
     void *d_disp, *d_disp_r, *d_labels, *d_sizes, *d_lut, *d_row_extras, *d_row_count;
-    void *d_snap_wta, *d_snap_lr, *d_snap_speckle;
+    void *d_snap_wta, *d_snap_lr, *d_snap_speckle, *d_totals, *d_median_scratch;
     size_t plane_bytes;
     /* pinned staging for the host-pointer entry point */
     void *h_left, *h_right, *h_disp;
@@ -151,7 +151,8 @@ static void free_device_buffers(sgm_instance* s)
 {
     void** all[] = {&s->d_left, &s->d_right, &s->d_census_l, &s->d_census_r, &s->d_cost, &s->d_planes, &s->d_extras,
                     &s->d_S, &s->d_disp, &s->d_disp_r, &s->d_labels, &s->d_sizes, &s->d_lut, &s->d_row_extras,
-                    &s->d_row_count, &s->d_snap_wta, &s->d_snap_lr, &s->d_snap_speckle};
+                    &s->d_row_count, &s->d_snap_wta, &s->d_snap_lr, &s->d_snap_speckle, &s->d_totals,
+                    &s->d_median_scratch};
     for (size_t i = 0; i < sizeof all / sizeof all[0]; ++i) {
         sgmd_free(s->device, *all[i]);
         *all[i] = NULL;
@@ -160,7 +161,7 @@ static void free_device_buffers(sgm_instance* s)
     sgmd_free_pinned(s->device, s->h_right);
     sgmd_free_pinned(s->device, s->h_disp);
     s->h_left = s->h_right = s->h_disp = NULL;
-    s->cap_px = s->cap_cells = s->cap_extras = 0;
+    s->cap_px = s->cap_cells = s->cap_extras = s->cap_median = 0;
     s->cap_H = s->cap_row_cap = 0;
     s->tab_W = s->tab_H = 0;
 }
@@ -275,6 +276,7 @@ static bool ensure_buffers(sgm_instance* s)
     rc |= sgmd_alloc(dev, &s->d_disp_r, px * 4);
     rc |= sgmd_alloc(dev, &s->d_labels, px * 4);
     rc |= sgmd_alloc(dev, &s->d_sizes, px * 4);
+    rc |= sgmd_alloc(dev, &s->d_totals, px * 4);
     rc |= sgmd_alloc(dev, &s->d_lut, 512);
     rc |= sgmd_alloc(dev, &s->d_snap_wta, px * 4);
     rc |= sgmd_alloc(dev, &s->d_snap_lr, px * 4);
@@ -323,6 +325,15 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
         s->d_extras = NULL;
         if (sgmd_alloc(s->device, &s->d_extras, extras_bytes) != 0) FAIL("device allocation failed (extras)");
         s->cap_extras = extras_bytes;
+    }
+    /* median scratch depends on W and H separately (64-row groups x time slots) */
+    const size_t median_bytes = sgmd_median_scratch_bytes(&s->g);
+    if (median_bytes > s->cap_median || !s->d_median_scratch) {
+        sgmd_stream_sync(s->device, s->stream);
+        sgmd_free(s->device, s->d_median_scratch);
+        s->d_median_scratch = NULL;
+        if (sgmd_alloc(s->device, &s->d_median_scratch, median_bytes) != 0) FAIL("device allocation failed (median scratch)");
+        s->cap_median = median_bytes;
     }
     s->plane_bytes = (size_t)width * height * s->g.Dp;
     /* a Reset with unchanged shape and penalties (the per-frame case, Q14) re-uploads nothing */
@@ -383,10 +394,10 @@ static bool run_pipeline(sgm_instance* s, const void* d_left, const void* d_righ
     if (s->keep_stages) rc |= sgmd_d2d_async(dev, st, s->d_snap_lr, d_out, px_bytes);
     mark(s, 6);
     if (o->is_remove_speckles)                                                                  /* .c:115 */
-        rc |= sgmd_speckle(dev, st, g, d_out, 1.0f, o->min_speckle_area, s->d_labels, s->d_sizes);
+        rc |= sgmd_speckle(dev, st, g, d_out, 1.0f, o->min_speckle_area, s->d_labels, s->d_sizes, s->d_totals);
     if (s->keep_stages) rc |= sgmd_d2d_async(dev, st, s->d_snap_speckle, d_out, px_bytes);
     mark(s, 7);
-    rc |= sgmd_median(dev, st, g, d_out);                                                       /* .c:120 */
+    rc |= sgmd_median(dev, st, g, d_out, s->d_median_scratch);                                                       /* .c:120 */
     mark(s, 8);
     if (rc != 0) FAIL("a kernel launch failed");
     return true;

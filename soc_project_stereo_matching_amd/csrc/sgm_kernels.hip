@@ -602,18 +602,29 @@ __global__ __launch_bounds__(256) void sgm_lrcheck_k(float* __restrict__ dl, con
 }
 
 // ============================================================================================
-// speckle removal  (ref :585-642): union-find connected-component labelling.  The reference's
+// speckle removal  (ref :585-642): connected-component labelling by union-find.  The reference's
 // breadth-first flood defines components of the symmetric relation "8-neighbours, both valid,
 // |delta| <= diff", so the result does not depend on traversal order.
+//
+// Two levels keep global atomics and pointer chasing rare: (A) every 64x16 tile is labelled
+// entirely in LDS and leaves one root per tile-local component, with its pixel count; (B) only
+// pixels on tile borders union roots across tiles in global memory; (C) every tile-local root adds
+// its count to its final root; (D) pixels whose component total is < min_area become +INF.
 // ============================================================================================
 
-static __device__ __forceinline__ int uf_find(const int* lab, int x)
+#define SPK_TW 64
+#define SPK_TH 16
+#define SPK_N (SPK_TW * SPK_TH)
+
+template <typename P>
+static __device__ __forceinline__ int uf_find(P lab, int x)
 {
     int p = __hip_atomic_load(lab + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     while (p != x) { x = p; p = __hip_atomic_load(lab + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
     return x;
 }
-static __device__ __forceinline__ void uf_union(int* lab, int a, int b)
+template <typename P>
+static __device__ __forceinline__ void uf_union(P lab, int a, int b)
 {
     for (;;) {
         a = uf_find(lab, a);
@@ -626,155 +637,263 @@ static __device__ __forceinline__ void uf_union(int* lab, int a, int b)
     }
 }
 
-__global__ __launch_bounds__(256) void sgm_speckle_init_k(const float* __restrict__ disp, int* __restrict__ lab,
-                                                          int* __restrict__ sizes, int n)
+static __device__ __forceinline__ bool spk_linked(float u, float v, float diff)
 {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= n) return;
-    lab[p] = (disp[p] == __builtin_inff()) ? -1 : p;
-    sizes[p] = 0;
+    const float inf = __builtin_inff();
+    return u != inf && v != inf && fabs((double)(u - v)) <= (double)diff;       // ref :622-624
 }
 
-__global__ __launch_bounds__(256) void sgm_speckle_merge_k(const float* __restrict__ disp, int* __restrict__ lab, int W,
-                                                           int H, float diff)
+// (A) label[p] = global pixel index of the tile-local root (or -1 for invalid pixels);
+//     local_size[p] = pixel count of the tile-local component for roots, 0 elsewhere; total[p] = 0
+__global__ __launch_bounds__(256) void sgm_speckle_tile_k(const float* __restrict__ disp, int* __restrict__ label,
+                                                          int* __restrict__ local_size, int* __restrict__ total, int W,
+                                                          int H, float diff)
+{
+    __shared__ float tile[SPK_N];
+    __shared__ int lab[SPK_N];
+    __shared__ int cnt[SPK_N];
+    const int tx0 = blockIdx.x * SPK_TW, ty0 = blockIdx.y * SPK_TH;
+    const float inf = __builtin_inff();
+    for (int i = threadIdx.x; i < SPK_N; i += 256) {
+        const int x = tx0 + (i & (SPK_TW - 1)), y = ty0 + (i / SPK_TW);
+        const float v = (x < W && y < H) ? disp[(size_t)y * W + x] : inf;
+        tile[i] = v;
+        lab[i] = (v == inf) ? -1 : i;
+        cnt[i] = 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SPK_N; i += 256) {
+        const float v = tile[i];
+        if (v == inf) continue;
+        const int lx = i & (SPK_TW - 1), ly = i / SPK_TW;
+        // the four already-scanned neighbours cover every 8-neighbour edge once
+        if (lx > 0 && spk_linked(tile[i - 1], v, diff)) uf_union(lab, i, i - 1);
+        if (ly > 0) {
+            if (spk_linked(tile[i - SPK_TW], v, diff)) uf_union(lab, i, i - SPK_TW);
+            if (lx > 0 && spk_linked(tile[i - SPK_TW - 1], v, diff)) uf_union(lab, i, i - SPK_TW - 1);
+            if (lx < SPK_TW - 1 && spk_linked(tile[i - SPK_TW + 1], v, diff)) uf_union(lab, i, i - SPK_TW + 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SPK_N; i += 256) {
+        if (lab[i] < 0) continue;
+        atomicAdd(&cnt[uf_find(lab, i)], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SPK_N; i += 256) {
+        const int x = tx0 + (i & (SPK_TW - 1)), y = ty0 + (i / SPK_TW);
+        if (x >= W || y >= H) continue;
+        const size_t p = (size_t)y * W + x;
+        int g = -1;
+        if (lab[i] >= 0) {
+            const int r = uf_find(lab, i);
+            g = (ty0 + r / SPK_TW) * W + tx0 + (r & (SPK_TW - 1));
+        }
+        label[p] = g;
+        local_size[p] = cnt[i];
+        total[p] = 0;
+    }
+}
+
+// (B) unions across tile borders (only pixels in the first row / first or last column of a tile have
+//     an already-scanned neighbour in another tile)
+__global__ __launch_bounds__(256) void sgm_speckle_border_k(const float* __restrict__ disp, int* __restrict__ label,
+                                                            int W, int H, float diff)
 {
     const int x = blockIdx.x * 256 + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= W) return;
+    const int lx = x & (SPK_TW - 1), ly = y & (SPK_TH - 1);
+    if (ly != 0 && lx != 0 && lx != SPK_TW - 1) return;
     const int p = y * W + x;
-    const float inf = __builtin_inff();
     const float v = disp[p];
-    if (v == inf) return;
-    // the four already-scanned neighbours cover every 8-neighbour edge once
+    if (v == __builtin_inff()) return;
     const int ox[4] = {-1, 0, 1, -1}, oy[4] = {-1, -1, -1, 0};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int xx = x + ox[k], yy = y + oy[k];
         if (xx < 0 || xx >= W || yy < 0) continue;
+        if ((xx / SPK_TW) == (x / SPK_TW) && (yy / SPK_TH) == (y / SPK_TH)) continue;   // same tile: done in (A)
         const int q = yy * W + xx;
-        const float u = disp[q];
-        if (u != inf && fabs((double)(u - v)) <= (double)diff) uf_union(lab, p, q);    // ref :622-624
+        if (spk_linked(disp[q], v, diff)) uf_union(label, p, q);
     }
 }
 
-__global__ __launch_bounds__(256) void sgm_speckle_count_k(int* __restrict__ lab, int* __restrict__ sizes, int n)
+// (C) every tile-local root adds its pixel count to the component's final root
+__global__ __launch_bounds__(256) void sgm_speckle_total_k(const int* __restrict__ label, const int* __restrict__ local_size,
+                                                           int* __restrict__ total, int n)
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
-    if (lab[p] < 0) return;
-    const int r = uf_find(lab, p);
-    atomicAdd(sizes + r, 1);
+    const int c = local_size[p];
+    if (c == 0) return;
+    int r = p;
+    for (int q = label[r]; q != r; q = label[r]) r = q;
+    atomicAdd(total + r, c);
 }
 
-__global__ __launch_bounds__(256) void sgm_speckle_apply_k(float* __restrict__ disp, const int* __restrict__ lab,
-                                                           const int* __restrict__ sizes, int n, unsigned min_area)
+// (D) ref :633
+__global__ __launch_bounds__(256) void sgm_speckle_apply_k(float* __restrict__ disp, const int* __restrict__ label,
+                                                           const int* __restrict__ total, int n, unsigned min_area)
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
-    if (lab[p] < 0) return;
-    const int r = uf_find(lab, p);
-    if ((unsigned)sizes[r] < min_area) disp[p] = __builtin_inff();           // ref :633
+    int r = label[p];
+    if (r < 0) return;
+    for (int q = label[r]; q != r; q = label[r]) r = q;
+    if ((unsigned)total[r] < min_area) disp[p] = __builtin_inff();
 }
 
 // ============================================================================================
 // in-place 3x3 median  (ref :525-557 with in == out, .c:120 -> raster-order recurrence, Q13)
 //
-// Output (y,x) sees filtered values at (y-1,x-1..x+1) and (y,x-1), originals elsewhere.  One
-// thread per image row, skewed by two columns per row, walks the rows as a wavefront: at step t
-// thread r is at column t - 2r + 1, so everything it needs from row y-1 was produced at least
-// one step earlier.  Filtered values travel to the row below through a 4-column LDS ring.
+// Output (y,x) is the 5th smallest of: filtered (y-1,x-1..x+1) and (y,x-1), originals (y,x),
+// (y,x+1), (y+1,x-1..x+1).  The recurrence is serial along x and y, so the kernel is built around
+// its critical path.  With the five originals pre-sorted (e0..e4, fully parallel pre-pass) and the
+// three values of the row above sorted (q0..q2), ranks 3 and 4 of those eight values are
+//   s3 = max(min(e3,q0), min(e2,q1), min(e1,q2), e0),  s4 = max(min(e4,q0), min(e3,q1), min(e2,q2), e1)
+// and the median of all nine is med3(s3, out(y,x-1), s4): ONE v_med3_f32 on the serial chain.
+// Rows map to lanes (64 rows per wave) skewed by 3 columns per row, so the value from the row
+// above is two steps old when it is needed and moves down one lane with a single DPP wave_shr.
+// Waves are decoupled: the last row of a wave feeds the first row of the next through an LDS ring
+// with progress counters.  The pre-pass stores its output time-skewed and lane-interleaved
+// ([band][t/4][e][lane][t%4], t = x + 3*lane), so every load of the serial kernel is a coalesced 1 KiB.
 // ============================================================================================
 
-static __device__ __forceinline__ void cswap(float& a, float& b)
+#define MED_SKEW 3
+#define MED_LAG (MED_SKEW * 63)
+#define MED_RING 128
+#define MED_WAVES 16
+
+static __device__ __forceinline__ void cswapf(float& a, float& b)
 {
     const float lo = fminf(a, b), hi = fmaxf(a, b);
     a = lo; b = hi;
 }
-// 5th smallest of 9 (ref :496-523); +INF orders last, NaN never occurs (Q15)
-static __device__ __forceinline__ float median9(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
-                                                float v7, float v8)
+
+// number of float4 time slots per band
+static inline int med_tq(int W) { return (W + MED_LAG + 3) / 4; }
+
+__global__ __launch_bounds__(64) void sgm_median_prep_k(const float* __restrict__ disp, float4* __restrict__ P, int W, int H,
+                                                        int Tq)
 {
-    cswap(v1, v2); cswap(v4, v5); cswap(v7, v8);
-    cswap(v0, v1); cswap(v3, v4); cswap(v6, v7);
-    cswap(v1, v2); cswap(v4, v5); cswap(v7, v8);
-    cswap(v0, v3); cswap(v5, v8); cswap(v4, v7);
-    cswap(v3, v6); cswap(v1, v4); cswap(v2, v5);
-    cswap(v4, v7); cswap(v4, v2); cswap(v6, v4);
-    cswap(v4, v2);
-    return v4;
+    const int l = threadIdx.x, tq = blockIdx.x, g = blockIdx.y;
+    const int y = 1 + 64 * g + l;
+    float e[5][4];
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[k][j] = 0.f;
+    if (y <= H - 2) {
+        const float* r0 = disp + (size_t)y * W;
+        const float* r1 = r0 + W;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = 4 * tq + j - MED_SKEW * l;
+            if (x < 0 || x > W - 1) continue;
+            if (x == 0 || x == W - 1) { e[0][j] = r0[x]; continue; }          // border column: passed through
+            float v0 = r0[x], v1 = r0[x + 1], v2 = r1[x - 1], v3 = r1[x], v4 = r1[x + 1];
+            cswapf(v0, v1); cswapf(v3, v4); cswapf(v2, v4); cswapf(v2, v3); cswapf(v1, v4);
+            cswapf(v0, v3); cswapf(v0, v2); cswapf(v1, v3); cswapf(v1, v2);
+            e[0][j] = v0; e[1][j] = v1; e[2][j] = v2; e[3][j] = v3; e[4][j] = v4;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        P[(((size_t)g * Tq + tq) * 5 + k) * 64 + l] = make_float4(e[k][0], e[k][1], e[k][2], e[k][3]);
 }
 
-#define MED_THREADS 1024
-#define MED_PF 8
-
-__global__ __launch_bounds__(MED_THREADS) void sgm_median_k(float* __restrict__ disp, int W, int H)
+__global__ __launch_bounds__(64 * MED_WAVES) void sgm_median_serial_k(float* __restrict__ disp, const float4* __restrict__ P,
+                                                                      int W, int H, int Tq)
 {
-    __shared__ float ring[MED_THREADS][4];
-    const int r = threadIdx.x;
-    const int rows = H - 2;                                        // interior rows 1..H-2
+    __shared__ __attribute__((aligned(16))) float ring[MED_WAVES][MED_RING];
+    __shared__ int prog[MED_WAVES];      // last column the wave's lane 63 has put into its ring
+    __shared__ int cons[MED_WAVES];      // last column the wave has taken from the ring of the wave above
+    const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int rows = H - 2;
     if (rows <= 0 || W <= 2) return;
-    for (int band = 0; band * MED_THREADS < rows; ++band) {
-        const int y = 1 + band * MED_THREADS + r;
-        const bool have_row = (y <= H - 2);
-        const int band_rows = min(MED_THREADS, rows - band * MED_THREADS);
-        const int nsteps = (W - 2) + 2 * (band_rows - 1);
-        const float* own = disp + (size_t)(have_row ? y : 1) * W;
-        const float* below = own + W;
-        const float* above = own - W;                              // read from memory only by thread 0 of the band
-        float left = own[0];                                       // in(y,0): border, never modified
-        float cur = own[1];
-        float b0 = below[0], b1 = below[1];
-        // originals of columns x+1 for the coming steps (own row and the row below)
-        float po[MED_PF], pbw[MED_PF];
-        // ring slot u is consumed at steps t == u (mod MED_PF); thread r starts at t = 2r, so its ring
-        // is rotated by 2r: slot u initially holds column 2 + ((u - 2r) mod MED_PF)
-#pragma unroll
-        for (int u = 0; u < MED_PF; ++u) {
-            const int c = 2 + ((u - 2 * r) & (MED_PF - 1));
-            po[u] = (c < W) ? own[c] : 0.f;
-            pbw[u] = (c < W) ? below[c] : 0.f;
-        }
+    const int groups = (rows + 63) / 64;
+    const int t_end = W + MED_LAG;                                   // lane 63 reaches column W-1 at t = W-1+MED_LAG
+
+    for (int gbase = 0; gbase < groups; gbase += MED_WAVES) {
+        if (threadIdx.x < MED_WAVES) { prog[threadIdx.x] = 0; cons[threadIdx.x] = 0; }
         __syncthreads();
-        for (int t0 = 0; t0 < nsteps; t0 += MED_PF) {
+        const int g = gbase + wv;
+        if (g < groups) {                                            // wave-uniform
+            const int y = 1 + 64 * g + l;
+            const bool valid = y <= H - 2;
+            const bool feeds_next = (wv + 1 < MED_WAVES) && (g + 1 < groups);
+            const bool top_from_ring = wv > 0;
+            const int yr = valid ? y : H - 2;
+            float* const out_row = disp + (size_t)yr * W;
+            const float* const top_row = disp + (size_t)(yr - 1) * W;
+            const float4* Pg = P + (size_t)g * Tq * 5 * 64 + l;
+
+            float o1 = 0.f, o2 = 0.f;                                // own outputs of the last two steps
+            float T0 = 0.f;                                          // out(y-1, x-1)
+            float T1 = top_row[0];                                   // out(y-1, x): column 0 is border, never modified
+
+            for (int t0 = 0; t0 < t_end; t0 += 4) {
+                // ---- flow control between waves (LDS only) ----
+                if (top_from_ring) {
+                    const int need = min(t0 + 4, W - 1);
+                    while (__hip_atomic_load(&prog[wv - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
+                        __builtin_amdgcn_s_sleep(1);
+                }
+                if (feeds_next) {
+                    const int last = t0 + 3 - MED_LAG;               // last column lane 63 writes in this batch
+                    while (__hip_atomic_load(&cons[wv + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < last - (MED_RING - 8))
+                        __builtin_amdgcn_s_sleep(1);
+                }
+                asm volatile("" ::: "memory");
+                // ---- inputs of the batch ----
+                float4 ev[5];
 #pragma unroll
-            for (int u = 0; u < MED_PF; ++u) {
-                const int t = t0 + u;
-                if (t < nsteps) {                                  // uniform
-                    const int x = t - 2 * r + 1;
-                    const bool on = have_row && x >= 1 && x <= W - 2;
-                    float outv = 0.f;
-                    if (on) {
-                        const float nxt = po[u], b2 = pbw[u];      // in(y,x+1), in(y+1,x+1)
-                        float a0, a1, a2;
-                        if (r == 0) {
-                            // row above the band: image border row or the finished last row of the previous band
-                            a0 = __hip_atomic_load(above + x - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            a1 = __hip_atomic_load(above + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            a2 = __hip_atomic_load(above + x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        } else {
-                            // filtered interior columns come from the ring; columns 0 and W-1 are border originals
-                            a0 = (x - 1 >= 1) ? ring[r - 1][(x - 1) & 3] : above[0];
-                            a1 = ring[r - 1][x & 3];
-                            a2 = (x + 1 <= W - 2) ? ring[r - 1][(x + 1) & 3] : above[W - 1];
-                        }
-                        outv = median9(a0, a1, a2, left, cur, nxt, b0, b1, b2);
-                        left = outv; cur = nxt; b0 = b1; b1 = b2;
-                        // refill the prefetch slot with column x + 1 + MED_PF
-                        const int c = x + 1 + MED_PF;
-                        po[u] = (c < W) ? own[c] : 0.f;
-                        pbw[u] = (c < W) ? below[c] : 0.f;
+                for (int k = 0; k < 5; ++k) ev[k] = Pg[((size_t)(t0 >> 2) * 5 + k) * 64];
+                float tv[4];                                         // lane 0: out(y-1, t0+1 .. t0+4)
+                if (top_from_ring) {
+                    const float4 r = *reinterpret_cast<const float4*>(&ring[wv - 1][t0 & (MED_RING - 1)]);
+                    tv[0] = r.x; tv[1] = r.y; tv[2] = r.z; tv[3] = r.w;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (l == 0) __hip_atomic_store(&cons[wv], t0 + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    // row above the band: the image's border row, or the finished last row of the previous band
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = min(t0 + 1 + j, W - 1);
+                        tv[j] = __hip_atomic_load(top_row + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
-                    if (on) {
-                        ring[r][x & 3] = outv;
-                        disp[(size_t)y * W + x] = outv;
-                    }
-                    // rows talk through the LDS ring only: wait for the LDS write, not for the global
-                    // prefetch loads / result stores still in flight (a __syncthreads() would drain them)
-                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int x = t0 + j - MED_SKEW * l;
+                    const float e0 = (&ev[0].x)[j], e1 = (&ev[1].x)[j], e2 = (&ev[2].x)[j], e3 = (&ev[3].x)[j],
+                                e4 = (&ev[4].x)[j];
+                    // out(y-1, x+1): produced by the lane above two steps ago (its o2); lane 0 takes the top row
+                    const float b = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(tv[j]), __float_as_int(o2),
+                                                                               0x138 /* wave_shr:1 */, 0xF, 0xF, false));
+                    const float lo = fminf(fminf(T0, T1), b), hi = fmaxf(fmaxf(T0, T1), b);
+                    const float mid = __builtin_amdgcn_fmed3f(T0, T1, b);
+                    const float s3 = fmaxf(fmaxf(fminf(e3, lo), fminf(e2, mid)), fmaxf(fminf(e1, hi), e0));
+                    const float s4 = fmaxf(fmaxf(fminf(e4, lo), fminf(e3, mid)), fmaxf(fminf(e2, hi), e1));
+                    const float m = __builtin_amdgcn_fmed3f(s3, o1, s4);
+                    const bool active = valid && x >= 0 && x <= W - 1;
+                    const bool interior = active && x >= 1 && x <= W - 2;
+                    const float outv = interior ? m : e0;           // border columns pass the original through
+                    if (interior) out_row[x] = outv;
+                    if (x >= 0) { T0 = T1; T1 = b; }
+                    o2 = o1; o1 = outv;
+                    if (feeds_next && l == 63 && x >= 1 && x <= W - 1) ring[wv][(x - 1) & (MED_RING - 1)] = outv;
+                }
+                if (feeds_next) {
+                    const int done = min(t0 + 3 - MED_LAG, W - 1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (l == 63 && done >= 1) __hip_atomic_store(&prog[wv], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
+            if (l == 0) __hip_atomic_store(&cons[wv], 0x7FFFFFF0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        __syncthreads();
+        __syncthreads();                                             // band finished and stored before the next one reads it
     }
 }
 
@@ -1013,26 +1132,43 @@ int sgmd_lrcheck(int ord, void* stream, const sgmd_geom* g, void* disp_l, const 
 }
 
 int sgmd_speckle(int ord, void* stream, const sgmd_geom* g, void* disp, float diff, unsigned min_area, void* labels,
-                 void* sizes)
+                 void* sizes, void* totals)
 {
     HIP_TRY(hipSetDevice(ord));
     hipStream_t st = (hipStream_t)stream;
     const int n = g->W * g->H;
     const dim3 lin((n + 255) / 256), b(256);
-    hipLaunchKernelGGL(sgm_speckle_init_k, lin, b, 0, st, (const float*)disp, (int*)labels, (int*)sizes, n);
-    hipLaunchKernelGGL(sgm_speckle_merge_k, dim3((g->W + 255) / 256, g->H), b, 0, st, (const float*)disp, (int*)labels,
+    hipLaunchKernelGGL(sgm_speckle_tile_k, dim3((g->W + SPK_TW - 1) / SPK_TW, (g->H + SPK_TH - 1) / SPK_TH), b, 0, st,
+                       (const float*)disp, (int*)labels, (int*)sizes, (int*)totals, g->W, g->H, diff);
+    hipLaunchKernelGGL(sgm_speckle_border_k, dim3((g->W + 255) / 256, g->H), b, 0, st, (const float*)disp, (int*)labels,
                        g->W, g->H, diff);
-    hipLaunchKernelGGL(sgm_speckle_count_k, lin, b, 0, st, (int*)labels, (int*)sizes, n);
-    hipLaunchKernelGGL(sgm_speckle_apply_k, lin, b, 0, st, (float*)disp, (const int*)labels, (const int*)sizes, n,
+    hipLaunchKernelGGL(sgm_speckle_total_k, lin, b, 0, st, (const int*)labels, (const int*)sizes, (int*)totals, n);
+    hipLaunchKernelGGL(sgm_speckle_apply_k, lin, b, 0, st, (float*)disp, (const int*)labels, (const int*)totals, n,
                        min_area);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-int sgmd_median(int ord, void* stream, const sgmd_geom* g, void* disp)
+size_t sgmd_median_scratch_bytes(const sgmd_geom* g)
+{
+    const int groups = (g->H - 2 + 63) / 64;
+    if (groups <= 0) return 16;
+    return (size_t)groups * med_tq(g->W) * 5 * 64 * sizeof(float4);
+}
+
+int sgmd_median(int ord, void* stream, const sgmd_geom* g, void* disp, void* scratch)
 {
     HIP_TRY(hipSetDevice(ord));
-    hipLaunchKernelGGL(sgm_median_k, dim3(1), dim3(MED_THREADS), 0, (hipStream_t)stream, (float*)disp, g->W, g->H);
+    const int rows = g->H - 2;
+    if (rows <= 0 || g->W <= 2) return 0;                            // no interior pixel: the filter is a no-op
+    const int groups = (rows + 63) / 64;
+    const int Tq = med_tq(g->W);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sgm_median_prep_k, dim3(Tq, groups), dim3(64), 0, st, (const float*)disp, (float4*)scratch, g->W,
+                       g->H, Tq);
+    const int waves = groups < MED_WAVES ? groups : MED_WAVES;
+    hipLaunchKernelGGL(sgm_median_serial_k, dim3(1), dim3(64 * waves), 0, st, (float*)disp, (const float4*)scratch, g->W,
+                       g->H, Tq);
     HIP_TRY(hipGetLastError());
     return 0;
 }

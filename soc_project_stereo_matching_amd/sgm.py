@@ -71,6 +71,7 @@ def load_library() -> C.CDLL:
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: build it with `make -C soc_project_stereo_matching_amd/csrc` "
                            "(needs hipcc); there is no CPU fallback")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(path)
     opt_p = C.c_void_p      # any ctypes structure with the SGMOption layout (28 bytes)
     for f in (L.SGM_Initialize, L.SGM_Reset):
@@ -115,6 +116,22 @@ def load_library() -> C.CDLL:
     L.sgm_host_p2_table.argtypes = [C.c_int, C.c_int, C.c_void_p]
     _LIB = L
     return L
+
+
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  The PyTorch-ROCm wheel bundles its own libamdhip64/libhsa; a
+    second runtime (the system one libsgm_mi355x.so is linked against) initialised in the same
+    process finds no GPU.  Python callers use torch for device memory and torch.distributed, so
+    before loading our library we promote torch's already-loaded runtime to the global symbol
+    scope: the HIP calls and the kernel registration of libsgm_mi355x.so then bind to it.  A plain C
+    caller (no torch in the process) simply gets the system runtime the library is linked to."""
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        return
+    bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(bundled):
+        C.CDLL(bundled, mode=C.RTLD_GLOBAL)
 
 
 def synth_pair(width, height, disparity_range, seed):
