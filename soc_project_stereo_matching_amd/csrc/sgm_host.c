@@ -305,6 +305,8 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
     s->g.DPL = pick_dpl(D);
     s->g.Dp = 16 * s->g.DPL;
     s->g.dmin = option->min_disparity;
+    if ((unsigned long long)width * height * (unsigned)s->g.Dp >= 0xFFFFFFFFull)
+        FAIL("cost volume too large: width*height*%d must stay below 2^32 cells (32-bit offsets in the kernels)", s->g.Dp);
 
     s->paths.ndirs = (s->honor_num_paths && option->num_paths == 4) ? 4 : 8;    /* Q1 */
     s->paths.p1 = option->p1;

@@ -56,13 +56,19 @@ enum : int {
     DPP_ROW_HALF_MIRROR = 0x141  // lane i <- lane 7-i (within each 8)
 };
 
-// min over the 16 lanes of a row, result in every lane of the row (4 DPP ops)
+// min over the 16 lanes of a row, result in every lane of the row (4 DPP steps; every source lane
+// exists for these permutations, so no `old` operand is needed and the move folds into v_min_u32_dpp)
+template <int CTRL>
+static __device__ __forceinline__ unsigned dpp_perm(unsigned src)
+{
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)src, CTRL, 0xF, 0xF, true);
+}
 static __device__ __forceinline__ unsigned row_allmin(unsigned v)
 {
-    v = min(v, dpp_mov<DPP_QUAD_XOR1>(v, v));
-    v = min(v, dpp_mov<DPP_QUAD_XOR2>(v, v));
-    v = min(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v, v));
-    v = min(v, dpp_mov<DPP_ROW_MIRROR>(v, v));
+    v = min(v, dpp_perm<DPP_QUAD_XOR1>(v));
+    v = min(v, dpp_perm<DPP_QUAD_XOR2>(v));
+    v = min(v, dpp_perm<DPP_ROW_HALF_MIRROR>(v));
+    v = min(v, dpp_perm<DPP_ROW_MIRROR>(v));
     return v;
 }
 
@@ -224,100 +230,119 @@ static __device__ __forceinline__ void pack_cells(const us2 (&pr)[DPL / 2], Cell
     }
 }
 
-// The reference's pointer walk for one line (ref :243-255 start, :281-323 step, :359-367 trackers).
-struct PathCursor {
-    int p;          // linear pixel index
-    int row, col;   // the two uint16_t trackers of the reference
-    bool dead;      // the walk left the image (Q6): the line ends
-};
-
+// One aggregation step for the 4 lines of a wave: returns the new packed L_r in Ln and the new
+// row minimum; Lp/min_prev are the previous pixel's (ref :329-353).
 template <int DPL, bool PAD>
-__global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
+static __device__ __forceinline__ unsigned agg_step(const CellVec<DPL>& cells, us2 (&Lp)[DPL / 2], unsigned min_prev,
+                                                    unsigned pen16, us2 p1v, const us2 (&padmask)[DPL / 2],
+                                                    CellVec<DPL>& packed_out)
 {
-    constexpr int NP = DPL / 2;     // packed pairs per lane
-    constexpr int PF = 4;           // software prefetch depth (steps)
-
-    __shared__ unsigned short lut_s[256];
-    const int lane = threadIdx.x;
+    constexpr int NP = DPL / 2;
+    us2 C[NP];
+    unpack_cells<DPL>(cells, C);
+    const unsigned l4u = (min_prev + pen16) & 0xFFFFu;                     // ref :335, truncated to u16
+    const us2 l4 = as_p(l4u | (l4u << 16));
+    const us2 mp = as_p(min_prev | (min_prev << 16));
+    // d-1 / d+1 neighbours across the lane boundary; 255 where there is none (ref :260-263)
+    const unsigned from_left = dpp_mov<DPP_ROW_SHR1>(0x00FF00FFu, as_u(Lp[NP - 1]));
+    const unsigned from_right = dpp_mov<DPP_ROW_SHL1>(0x00FF00FFu, as_u(Lp[0]));
+    us2 Ln[NP];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) lut_s[lane * 4 + i] = a.lut[lane * 4 + i];
-    __syncthreads();
+    for (int j = 0; j < NP; ++j) {
+        const unsigned below = (j == 0) ? from_left : as_u(Lp[j - 1]);
+        const unsigned above = (j == NP - 1) ? from_right : as_u(Lp[j + 1]);
+        const us2 dm1 = as_p(__builtin_amdgcn_alignbit(as_u(Lp[j]), below, 16));   // (Lp(d-1), Lp(d))   pairs
+        const us2 dp1 = as_p(__builtin_amdgcn_alignbit(above, as_u(Lp[j]), 16));   // (Lp(d+1), Lp(d+2))
+        us2 m = pk_min(dm1 + p1v, dp1 + p1v);           // l2, l3 (ref :333-334), each truncated to u16
+        m = pk_min(m, Lp[j]);                           // l1
+        m = pk_min(m, l4);
+        const us2 wide = (C[j] - mp) + m;               // mod 2^16 == the C's int arithmetic mod 2^16
+        unsigned r = as_u(wide) & 0x00FF00FFu;          // ref :343 uint8 truncation (Q7)
+        if (PAD) r |= as_u(padmask[j]);
+        Ln[j] = as_p(r);
+    }
+    us2 m = Ln[0];
+#pragma unroll
+    for (int j = 1; j < NP; ++j) m = pk_min(m, Ln[j]);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) Lp[j] = Ln[j];
+    pack_cells<DPL>(Ln, packed_out);
+    return row_allmin(min(as_u(m) & 0xFFFFu, as_u(m) >> 16));             // ref :347,353
+}
 
-    // which direction does this block belong to (wave-uniform)
-    const int b = blockIdx.x;
-    int dir = 0;
-    while (dir + 1 < a.ndirs && b >= a.block_begin[dir + 1]) ++dir;
-    const int grp = b - a.block_begin[dir];
+enum { AGG_H = 0, AGG_V = 1, AGG_D = 2 };
+
+// Regular lines of one direction kind.  All addressing is 32-bit offsets from the volume bases
+// (the host guarantees W*H*Dp < 2^32); the walk is the reference's (ref :281-323, 359-367) with the
+// row test dropped (a regular line is never in the last row before its final step) and the two
+// edge tests turned into selects.
+template <int DPL, bool PAD, int KIND>
+static __device__ __forceinline__ void agg_regular(const AggArgs& a, const unsigned short* lut_s, int dir, int grp)
+{
+    constexpr int NP = DPL / 2;
+    constexpr int NW = (DPL + 3) / 4;
+    constexpr int PF = 4;                                                  // software prefetch depth (steps)
+    const int lane = threadIdx.x;
     const int dx = a.dx[dir], dy = a.dy[dir];
     const int W = a.W, H = a.H, Dp = a.Dp;
     const bool fwd = (dx == 1 && dy == 0) || (dx == 0 && dy == 1) || (dx == 1 && dy == 1) || (dx == -1 && dy == 1);  // ref :232
     const int s = fwd ? 1 : -1;
-    const bool horizontal = (dy == 0), vertical = (dx == 0);
-    const int diag_step = s * (W + ((dx == dy) ? 1 : -1));        // ref :311-322
-    const int col_step = (dx == dy) ? s : -s;                      // ref :360-367
-    const int nlines = horizontal ? H : W;                         // ref :238
-    const int nsteps = (horizontal ? W : H) - 1;                   // ref :281
-    const int npx = W * H;
+    const int nlines = (KIND == AGG_H) ? H : W;                            // ref :238
+    const int nsteps = ((KIND == AGG_H) ? W : H) - 1;                      // ref :281
+    if (KIND == AGG_D && W < 2) return;                                    // the only line is the anomalous one
 
     const int sub = lane & 15;
     int line = grp * 4 + (lane >> 4);
-    const bool active = line < nlines;
-    if (!active) line = nlines - 1;                                // keep the wave convergent; stores are masked
-    const bool anom = active && (line == a.anom_line[dir]);
-    const int slot = dir - 4;                                      // diagonal slot of the extras buffer
-
+    bool store_ok = line < nlines;
+    if (!store_ok) line = nlines - 1;                                      // keep the wave convergent; stores are masked
+    if (KIND == AGG_D && line == a.anom_line[dir]) {                       // handled by agg_anomalous()
+        store_ok = false;
+        line = (line == 0) ? 1 : line - 1;
+    }
+    const unsigned lane_off = (unsigned)(sub * DPL);
     uint8_t* const plane = a.planes + (size_t)dir * a.plane_bytes;
-    const int lane_off = sub * DPL;
 
-    // padded disparity slots (d >= D) are forced to 255: neutral for the min and exactly the
-    // Lp(D) sentinel the last real disparity needs
     us2 padmask[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        const unsigned lo = (lane_off + 2 * j >= a.D) ? 0x00FFu : 0u;
-        const unsigned hi = (lane_off + 2 * j + 1 >= a.D) ? 0x00FF0000u : 0u;
+        const unsigned lo = ((int)lane_off + 2 * j >= a.D) ? 0x00FFu : 0u;
+        const unsigned hi = ((int)lane_off + 2 * j + 1 >= a.D) ? 0x00FF0000u : 0u;
         padmask[j] = as_p(lo | hi);
     }
 
-    PathCursor fc;
-    if (horizontal) fc.p = line * W + (fwd ? 0 : W - 1);
-    else            fc.p = (fwd ? 0 : (H - 1) * W) + line;
-    fc.row = fwd ? 0 : H - 1;
-    fc.col = line;
-    fc.dead = false;
+    // fetch cursor: pixel index p (grey value) and byte offset of this lane's cells
+    unsigned p, off;
+    unsigned rowpix = 0, rowoff = 0, pcol = 0, col = 0;                    // AGG_D only
+    int dstep_p = 0, dstep_off = 0;
+    if (KIND == AGG_H) {
+        p = (unsigned)(line * W + (fwd ? 0 : W - 1));
+        dstep_p = s; dstep_off = s * Dp;
+    } else if (KIND == AGG_V) {
+        p = (unsigned)((fwd ? 0 : (H - 1) * W) + line);
+        dstep_p = s * W; dstep_off = s * W * Dp;
+    } else {
+        rowpix = (unsigned)(fwd ? 0 : (H - 1) * W);
+        rowoff = rowpix * (unsigned)Dp;
+        pcol = col = (unsigned)line;
+        p = rowpix + pcol;
+        dstep_p = s * W; dstep_off = s * W * Dp;
+    }
+    off = p * (unsigned)Dp + lane_off;
+    const int col_step = (dx == dy) ? s : -s;                              // ref :360-367
 
-    auto advance = [&](PathCursor& c) {
-        if (horizontal) {
-            c.p += s;
-        } else if (vertical) {
-            c.p += s * W;
+    auto advance = [&]() {
+        if (KIND != AGG_D) {
+            p += (unsigned)dstep_p;
+            off += (unsigned)dstep_off;
         } else {
-            const bool not_last = fwd ? (c.row < H - 1) : (c.row > 0);
-            if (c.col == W - 1 && not_last)      { c.p = (c.row + s) * W;           c.col = 0; }
-            else if (c.col == 0 && not_last)     { c.p = (c.row + s) * W + (W - 1); c.col = W - 1; }
-            else                                 { c.p += diag_step; }
-            c.row = (c.row + s) & 0xFFFF;
-            c.col = (c.col + col_step) & 0xFFFF;
-        }
-        if (c.p < 0 || c.p >= npx) c.dead = true;                  // only anomalous lines can get here
-    };
-
-    // where the L_r of step k goes: the direction's plane, or (anomalous line) the extras row k
-    auto out_ptr = [&](int p, int k) -> uint8_t* {
-        return anom ? a.extras + ((size_t)slot * H + k) * Dp + lane_off : plane + (size_t)p * Dp + lane_off;
-    };
-    // cells no regular line of this direction visits (the track the anomalous line should have
-    // taken) are zeroed by the anomalous line's lanes
-    auto ghost_zero = [&](int k) {
-        if (anom && a.ghost_zero) {
-            int gc = line + dx * k;
-            if (gc >= W) gc -= W;
-            if (gc < 0) gc += W;
-            const int gr = fwd ? k : H - 1 - k;
-            CellVec<DPL> z;
-#pragma unroll
-            for (int i = 0; i < (DPL + 3) / 4; ++i) z.w[i] = 0;
-            store_cells<DPL>(plane + ((size_t)gr * W + gc) * Dp + lane_off, z);
+            const bool wr = (col == (unsigned)(W - 1));                    // ref :297 (tracker, not true column)
+            const bool wl = !wr && (col == 0);                             // ref :304
+            pcol = wr ? 0u : (wl ? (unsigned)(W - 1) : pcol + (unsigned)col_step);
+            col = ((wr ? 0u : (wl ? (unsigned)(W - 1) : col)) + (unsigned)col_step) & 0xFFFFu;
+            rowpix += (unsigned)dstep_p;
+            rowoff += (unsigned)dstep_off;
+            p = rowpix + pcol;
+            off = rowoff + __umul24(pcol, (unsigned)Dp) + lane_off;
         }
     };
 
@@ -327,8 +352,8 @@ __global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
     int g_prev;
     {
         CellVec<DPL> c0;
-        load_cells<DPL>(a.cost + (size_t)fc.p * Dp + lane_off, c0);
-        g_prev = a.img[fc.p];
+        load_cells<DPL>(a.cost + off, c0);
+        g_prev = a.img[p];
         unpack_cells<DPL>(c0, Lp);
         if (PAD) {
 #pragma unroll
@@ -338,93 +363,180 @@ __global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
 #pragma unroll
         for (int j = 1; j < NP; ++j) m = pk_min(m, Lp[j]);
         min_prev = row_allmin(min(as_u(m) & 0xFFFFu, as_u(m) >> 16));
-        if (active) {
+        if (store_ok) {
             CellVec<DPL> o;
             pack_cells<DPL>(Lp, o);
-            store_cells<DPL>(out_ptr(fc.p, 0), o);
+            store_cells<DPL>(plane + off, o);
+        }
+    }
+
+    // ---- prefetch ring ----
+    CellVec<DPL> cb[PF];
+    int gb[PF];
+    unsigned ob[PF];
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        gb[u] = 0; ob[u] = off;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) cb[u].w[i] = 0;
+        if (1 + u <= nsteps) {
+            advance();
+            ob[u] = off;
+            load_cells<DPL>(a.cost + off, cb[u]);
+            gb[u] = a.img[p];
+        }
+    }
+    const us2 p1v = splat((unsigned)a.p1);
+
+    // one step on ring slot u; `refill` = also fetch step k + PF into the slot
+    auto step = [&](int u, bool refill) {
+        const CellVec<DPL> cells = cb[u];
+        const int g = gb[u];
+        const unsigned o = ob[u];
+        if (refill) {
+            advance();
+            ob[u] = off;
+            load_cells<DPL>(a.cost + off, cb[u]);
+            gb[u] = a.img[p];
+        }
+        const int dg = g > g_prev ? g - g_prev : g_prev - g;
+        CellVec<DPL> packed;
+        min_prev = agg_step<DPL, PAD>(cells, Lp, min_prev, lut_s[dg], p1v, padmask, packed);
+        g_prev = g;
+        if (store_ok) store_cells<DPL>(plane + o, packed);
+    };
+    // hot loop: all PF steps and all PF refills are in range, no per-step conditions
+    int k0 = 1;
+    for (; k0 + 2 * PF - 1 <= nsteps; k0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) step(u, true);
+    }
+    // tail: at most 2*PF-1 steps
+    for (; k0 <= nsteps; k0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            if (k0 + u <= nsteps) step(u, k0 + u + PF <= nsteps);
+    }
+}
+
+// The anomalous line of a diagonal direction: walked with the reference's full state
+// machine incl. the out-of-image end (Q6); its L_r go to the extras rows (the pixels it visits are
+// also visited by regular lines), and it zeroes the cells no line visits (W >= H: the track it
+// should have taken).  One wave per diagonal direction; all four DPP rows compute the same line,
+// row 0 stores.
+template <int DPL, bool PAD>
+static __device__ __forceinline__ void agg_anomalous(const AggArgs& a, const unsigned short* lut_s, int dir)
+{
+    constexpr int NP = DPL / 2;
+    constexpr int NW = (DPL + 3) / 4;
+    const int lane = threadIdx.x;
+    const int dx = a.dx[dir], dy = a.dy[dir];
+    const int W = a.W, H = a.H, Dp = a.Dp;
+    const bool fwd = (dx == 1 && dy == 1) || (dx == -1 && dy == 1);
+    const int s = fwd ? 1 : -1;
+    const int diag_step = s * (W + ((dx == dy) ? 1 : -1));                 // ref :311-322
+    const int col_step = (dx == dy) ? s : -s;
+    const int nsteps = H - 1;
+    const long long npx = (long long)W * H;
+    const int line = a.anom_line[dir];
+    const int slot = dir - 4;
+    const bool store_ok = lane < 16;
+    const unsigned lane_off = (unsigned)((lane & 15) * DPL);
+    uint8_t* const plane = a.planes + (size_t)dir * a.plane_bytes;
+    uint8_t* const extras = a.extras + (size_t)slot * H * Dp + lane_off;
+
+    us2 padmask[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const unsigned lo = ((int)lane_off + 2 * j >= a.D) ? 0x00FFu : 0u;
+        const unsigned hi = ((int)lane_off + 2 * j + 1 >= a.D) ? 0x00FF0000u : 0u;
+        padmask[j] = as_p(lo | hi);
+    }
+    auto ghost_zero = [&](int k) {
+        if (store_ok && a.ghost_zero) {
+            int gc = line + dx * k;
+            if (gc >= W) gc -= W;
+            if (gc < 0) gc += W;
+            const int gr = fwd ? k : H - 1 - k;
+            CellVec<DPL> z;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) z.w[i] = 0;
+            store_cells<DPL>(plane + ((size_t)gr * W + gc) * Dp + lane_off, z);
+        }
+    };
+
+    long long p = (fwd ? 0 : (long long)(H - 1) * W) + line;
+    int row = fwd ? 0 : H - 1, col = line;
+    us2 Lp[NP];
+    unsigned min_prev;
+    int g_prev;
+    {
+        CellVec<DPL> c0;
+        load_cells<DPL>(a.cost + (size_t)p * Dp + lane_off, c0);
+        g_prev = a.img[p];
+        unpack_cells<DPL>(c0, Lp);
+        if (PAD) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) Lp[j] = as_p(as_u(Lp[j]) | as_u(padmask[j]));
+        }
+        us2 m = Lp[0];
+#pragma unroll
+        for (int j = 1; j < NP; ++j) m = pk_min(m, Lp[j]);
+        min_prev = row_allmin(min(as_u(m) & 0xFFFFu, as_u(m) >> 16));
+        if (store_ok) {
+            CellVec<DPL> o;
+            pack_cells<DPL>(Lp, o);
+            store_cells<DPL>(extras, o);
         }
         ghost_zero(0);
     }
-
-    // ---- prefetch ring: cost cells, grey value and pixel index of the next PF steps ----
-    CellVec<DPL> cb[PF];
-    int gb[PF], pb[PF];
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        pb[u] = -1; gb[u] = 0;
-#pragma unroll
-        for (int i = 0; i < (DPL + 3) / 4; ++i) cb[u].w[i] = 0;
-        if (1 + u <= nsteps) {
-            if (!fc.dead) advance(fc);
-            pb[u] = fc.dead ? -1 : fc.p;
-            const int q = fc.dead ? 0 : fc.p;
-            load_cells<DPL>(a.cost + (size_t)q * Dp + lane_off, cb[u]);
-            gb[u] = a.img[q];
-        }
-    }
-
     const us2 p1v = splat((unsigned)a.p1);
-    bool line_dead = false;
-
-    for (int k0 = 1; k0 <= nsteps; k0 += PF) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u) {
-            const int k = k0 + u;
-            if (k <= nsteps) {                                      // wave-uniform
-                const int p = pb[u];
-                const int g = gb[u];
-                us2 C[NP];
-                unpack_cells<DPL>(cb[u], C);
-                // refill this ring slot for step k + PF
-                if (k + PF <= nsteps) {
-                    if (!fc.dead) advance(fc);
-                    pb[u] = fc.dead ? -1 : fc.p;
-                    const int q = fc.dead ? 0 : fc.p;
-                    load_cells<DPL>(a.cost + (size_t)q * Dp + lane_off, cb[u]);
-                    gb[u] = a.img[q];
-                }
-                if (p < 0) line_dead = true;                        // Q6: the line ended
-
-                const int dg = g > g_prev ? g - g_prev : g_prev - g;
-                const us2 l4 = splat(min_prev + (unsigned)lut_s[dg]);         // ref :335, truncated to u16
-                const us2 mp = splat(min_prev);
-
-                // d-1 / d+1 neighbours across the lane boundary; 255 where there is none (ref :260-263)
-                const unsigned from_left = dpp_mov<DPP_ROW_SHR1>(0x00FF00FFu, as_u(Lp[NP - 1]));
-                const unsigned from_right = dpp_mov<DPP_ROW_SHL1>(0x00FF00FFu, as_u(Lp[0]));
-
-                us2 Ln[NP];
-#pragma unroll
-                for (int j = 0; j < NP; ++j) {
-                    const unsigned below = (j == 0) ? from_left : as_u(Lp[j - 1]);
-                    const unsigned above = (j == NP - 1) ? from_right : as_u(Lp[j + 1]);
-                    const us2 dm1 = as_p(__builtin_amdgcn_alignbit(as_u(Lp[j]), below, 16));   // (Lp(d-1), Lp(d))   pairs
-                    const us2 dp1 = as_p(__builtin_amdgcn_alignbit(above, as_u(Lp[j]), 16));   // (Lp(d+1), Lp(d+2))
-                    us2 m = pk_min(dm1 + p1v, dp1 + p1v);           // l2, l3 (ref :333-334), u16 wrap
-                    m = pk_min(m, Lp[j]);                           // l1
-                    m = pk_min(m, l4);
-                    const us2 wide = C[j] + m - mp;                 // mod 2^16 == the C's int arithmetic mod 2^16
-                    unsigned r = as_u(wide) & 0x00FF00FFu;          // ref :343 uint8 truncation (Q7)
-                    if (PAD) r |= as_u(padmask[j]);
-                    Ln[j] = as_p(r);
-                }
-                us2 m = Ln[0];
-#pragma unroll
-                for (int j = 1; j < NP; ++j) m = pk_min(m, Ln[j]);
-                min_prev = row_allmin(min(as_u(m) & 0xFFFFu, as_u(m) >> 16));   // ref :347,353
-#pragma unroll
-                for (int j = 0; j < NP; ++j) Lp[j] = Ln[j];
-                g_prev = g;
-
-                if (active && !line_dead) {
-                    CellVec<DPL> o;
-                    pack_cells<DPL>(Ln, o);
-                    store_cells<DPL>(out_ptr(p, k), o);
-                }
-                ghost_zero(k);
-            }
+    bool dead = false;
+    for (int k = 1; k <= nsteps; ++k) {
+        if (!dead) {
+            const bool not_last = fwd ? (row < H - 1) : (row > 0);
+            if (col == W - 1 && not_last)      { p = (long long)(row + s) * W;           col = 0; }       // ref :297-303
+            else if (col == 0 && not_last)     { p = (long long)(row + s) * W + (W - 1); col = W - 1; }   // ref :304-310
+            else                               { p += diag_step; }
+            row = (row + s) & 0xFFFF;
+            col = (col + col_step) & 0xFFFF;
+            if (p < 0 || p >= npx) dead = true;                            // Q6: the line ends
         }
+        if (!dead) {                                                       // uniform (all rows walk the same line)
+            CellVec<DPL> cells, packed;
+            load_cells<DPL>(a.cost + (size_t)p * Dp + lane_off, cells);
+            const int g = a.img[p];
+            const int dg = g > g_prev ? g - g_prev : g_prev - g;
+            min_prev = agg_step<DPL, PAD>(cells, Lp, min_prev, lut_s[dg], p1v, padmask, packed);
+            g_prev = g;
+            if (store_ok) store_cells<DPL>(extras + (size_t)k * Dp, packed);
+        }
+        ghost_zero(k);
     }
+}
+
+template <int DPL, bool PAD>
+__global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
+{
+    __shared__ unsigned short lut_s[256];
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lut_s[lane * 4 + i] = a.lut[lane * 4 + i];
+    __syncthreads();
+
+    // blocks [block_begin[d], block_begin[d+1]) are the regular lines of direction d; the last
+    // blocks (one per diagonal direction) are the anomalous lines
+    const int b = blockIdx.x;
+    if (b >= a.block_begin[8]) {
+        agg_anomalous<DPL, PAD>(a, lut_s, 4 + (b - a.block_begin[8]));
+        return;
+    }
+    int dir = 0;
+    while (dir + 1 < a.ndirs && b >= a.block_begin[dir + 1]) ++dir;
+    const int grp = b - a.block_begin[dir];
+    if (a.dy[dir] == 0)      agg_regular<DPL, PAD, AGG_H>(a, lut_s, dir, grp);
+    else if (a.dx[dir] == 0) agg_regular<DPL, PAD, AGG_V>(a, lut_s, dir, grp);
+    else                     agg_regular<DPL, PAD, AGG_D>(a, lut_s, dir, grp);
 }
 
 // ============================================================================================
@@ -764,6 +876,7 @@ __global__ __launch_bounds__(256) void sgm_speckle_apply_k(float* __restrict__ d
 #define MED_LAG (MED_SKEW * 63)
 #define MED_RING 128
 #define MED_WAVES 16
+#define MED_PF 4                 // batches of pre-sorted inputs kept in flight per wave
 
 static __device__ __forceinline__ void cswapf(float& a, float& b)
 {
@@ -832,8 +945,24 @@ __global__ __launch_bounds__(64 * MED_WAVES) void sgm_median_serial_k(float* __r
             float o1 = 0.f, o2 = 0.f;                                // own outputs of the last two steps
             float T0 = 0.f;                                          // out(y-1, x-1)
             float T1 = top_row[0];                                   // out(y-1, x): column 0 is border, never modified
+            // First wave of a band: the row above (image border row, or the finished last row of the
+            // previous band) is read 64 columns at a time, one chunk ahead; lane i of chunk k holds
+            // column 64k+1+i of the row above lane 0.
+            const float* const top0 = disp + (size_t)(64 * g) * W;   // row above this wave's lane 0
+            float chunk_cur = 0.f, chunk_nxt = 0.f;
+            if (!top_from_ring) chunk_nxt = __hip_atomic_load(top0 + min(1 + l, W - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-            for (int t0 = 0; t0 < t_end; t0 += 4) {
+            // pre-sorted neighbourhoods are read-only input: keep MED_PF batches (4 steps each) in flight
+            float4 evr[MED_PF][5];
+            auto load_batch = [&](float4 (&dst)[5], int t0) {
+                const int tq = min(t0 >> 2, Tq - 1);
+#pragma unroll
+                for (int k = 0; k < 5; ++k) dst[k] = Pg[((size_t)tq * 5 + k) * 64];
+            };
+#pragma unroll
+            for (int u = 0; u < MED_PF; ++u) load_batch(evr[u], 4 * u);
+
+            auto run_batch = [&](const float4 (&ev)[5], int t0) {
                 // ---- flow control between waves (LDS only) ----
                 if (top_from_ring) {
                     const int need = min(t0 + 4, W - 1);
@@ -846,10 +975,6 @@ __global__ __launch_bounds__(64 * MED_WAVES) void sgm_median_serial_k(float* __r
                         __builtin_amdgcn_s_sleep(1);
                 }
                 asm volatile("" ::: "memory");
-                // ---- inputs of the batch ----
-                float4 ev[5];
-#pragma unroll
-                for (int k = 0; k < 5; ++k) ev[k] = Pg[((size_t)(t0 >> 2) * 5 + k) * 64];
                 float tv[4];                                         // lane 0: out(y-1, t0+1 .. t0+4)
                 if (top_from_ring) {
                     const float4 r = *reinterpret_cast<const float4*>(&ring[wv - 1][t0 & (MED_RING - 1)]);
@@ -857,12 +982,13 @@ __global__ __launch_bounds__(64 * MED_WAVES) void sgm_median_serial_k(float* __r
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (l == 0) __hip_atomic_store(&cons[wv], t0 + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else {
-                    // row above the band: the image's border row, or the finished last row of the previous band
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int c = min(t0 + 1 + j, W - 1);
-                        tv[j] = __hip_atomic_load(top_row + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((t0 & 63) == 0) {
+                        chunk_cur = chunk_nxt;
+                        chunk_nxt = __hip_atomic_load(top0 + min(t0 + 64 + 1 + l, W - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        tv[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(chunk_cur), (t0 & 63) + j));
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -889,6 +1015,17 @@ __global__ __launch_bounds__(64 * MED_WAVES) void sgm_median_serial_k(float* __r
                     const int done = min(t0 + 3 - MED_LAG, W - 1);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (l == 63 && done >= 1) __hip_atomic_store(&prog[wv], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            };
+
+            for (int tb = 0; tb < t_end; tb += 4 * MED_PF) {
+#pragma unroll
+                for (int u = 0; u < MED_PF; ++u) {
+                    const int t0 = tb + 4 * u;
+                    if (t0 < t_end) {                                // wave-uniform
+                        run_batch(evr[u], t0);
+                        load_batch(evr[u], t0 + 4 * MED_PF);
+                    }
                 }
             }
             if (l == 0) __hip_atomic_store(&cons[wv], 0x7FFFFFF0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1079,6 +1216,7 @@ int sgmd_aggregate(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* 
         }
     }
     a.block_begin[8] = blocks;
+    if (paths->ndirs > 4) blocks += 4;                 // one extra wave per diagonal direction: its anomalous line
     const bool pad = (g->D != g->Dp);
     hipStream_t st = (hipStream_t)stream;
     switch (g->DPL) {
