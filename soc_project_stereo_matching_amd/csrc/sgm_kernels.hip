@@ -187,24 +187,32 @@ static __device__ __forceinline__ void load_cells(const uint8_t* p, CellVec<DPL>
     }
 }
 
+// L_r planes are written once and read once by the sum kernel: stream them past the caches (nt) so the
+// cost volume, which all eight directions re-read, keeps its place in L2 / Infinity Cache.
 template <int DPL>
 static __device__ __forceinline__ void store_cells(uint8_t* p, const CellVec<DPL>& v)
 {
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
     if constexpr (DPL == 2) {
-        *reinterpret_cast<unsigned short*>(p) = (unsigned short)v.w[0];
+        __builtin_nontemporal_store((unsigned short)v.w[0], reinterpret_cast<unsigned short*>(p));
     } else if constexpr (DPL == 4) {
-        *reinterpret_cast<unsigned*>(p) = v.w[0];
+        __builtin_nontemporal_store(v.w[0], reinterpret_cast<unsigned*>(p));
     } else if constexpr (DPL == 8) {
-        *reinterpret_cast<uint2*>(p) = make_uint2(v.w[0], v.w[1]);
+        v2u t = {v.w[0], v.w[1]};
+        __builtin_nontemporal_store(t, reinterpret_cast<v2u*>(p));
     } else if constexpr (DPL == 12) {
-        struct __attribute__((packed, aligned(4))) u3 { unsigned a, b, c; };
-        u3 t; t.a = v.w[0]; t.b = v.w[1]; t.c = v.w[2];
-        *reinterpret_cast<u3*>(p) = t;
+        v2u t = {v.w[0], v.w[1]};
+        __builtin_nontemporal_store(t, reinterpret_cast<v2u*>(p));
+        __builtin_nontemporal_store(v.w[2], reinterpret_cast<unsigned*>(p + 8));
     } else if constexpr (DPL == 16) {
-        *reinterpret_cast<uint4*>(p) = make_uint4(v.w[0], v.w[1], v.w[2], v.w[3]);
+        v4u t = {v.w[0], v.w[1], v.w[2], v.w[3]};
+        __builtin_nontemporal_store(t, reinterpret_cast<v4u*>(p));
     } else {
-        *reinterpret_cast<uint4*>(p) = make_uint4(v.w[0], v.w[1], v.w[2], v.w[3]);
-        *reinterpret_cast<uint4*>(p + 16) = make_uint4(v.w[4], v.w[5], v.w[6], v.w[7]);
+        v4u t = {v.w[0], v.w[1], v.w[2], v.w[3]};
+        v4u u = {v.w[4], v.w[5], v.w[6], v.w[7]};
+        __builtin_nontemporal_store(t, reinterpret_cast<v4u*>(p));
+        __builtin_nontemporal_store(u, reinterpret_cast<v4u*>(p + 16));
     }
 }
 
@@ -567,7 +575,9 @@ __global__ __launch_bounds__(256) void sgm_sum_k(const uint8_t* __restrict__ pla
         for (int i = 0; i < 8; ++i) acc[i] = 0;
     }
     auto add8 = [&](const uint8_t* p) {
-        const uint2 v = *reinterpret_cast<const uint2*>(p);
+        typedef unsigned v2u __attribute__((ext_vector_type(2)));
+        const v2u vv = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(p));    // read once
+        const uint2 v = make_uint2(vv.x, vv.y);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             acc[i] += (v.x >> (8 * i)) & 0xFF;
@@ -872,11 +882,12 @@ __global__ __launch_bounds__(256) void sgm_speckle_apply_k(float* __restrict__ d
 // ([band][t/4][e][lane][t%4], t = x + 3*lane), so every load of the serial kernel is a coalesced 1 KiB.
 // ============================================================================================
 
+#define MED_PF 4                 // batches (4 steps each) of pre-sorted inputs kept in flight per wave
+#define MED_NE 6                 // float4 planes per time slot: 5 pre-sorted originals + the row above a band
 #define MED_SKEW 3
 #define MED_LAG (MED_SKEW * 63)
 #define MED_RING 128
 #define MED_WAVES 16
-#define MED_PF 4                 // batches of pre-sorted inputs kept in flight per wave
 
 static __device__ __forceinline__ void cswapf(float& a, float& b)
 {
@@ -885,24 +896,30 @@ static __device__ __forceinline__ void cswapf(float& a, float& b)
 }
 
 // number of float4 time slots per band
-static inline int med_tq(int W) { return (W + MED_LAG + 3) / 4; }
+// (the time axis is padded to whole groups of MED_PF batches so the serial loop has no tail conditions:
+// hipcc's s_waitcnt insertion merges over every CFG path, and a skippable batch would force vmcnt(0))
+static inline int med_tq(int W) { return ((W + MED_LAG + 4 * MED_PF - 1) / (4 * MED_PF)) * MED_PF; }
 
 __global__ __launch_bounds__(64) void sgm_median_prep_k(const float* __restrict__ disp, float4* __restrict__ P, int W, int H,
                                                         int Tq)
 {
     const int l = threadIdx.x, tq = blockIdx.x, g = blockIdx.y;
     const int y = 1 + 64 * g + l;
-    float e[5][4];
+    float e[MED_NE][4];
 #pragma unroll
-    for (int k = 0; k < 5; ++k)
+    for (int k = 0; k < MED_NE; ++k)
 #pragma unroll
         for (int j = 0; j < 4; ++j) e[k][j] = 0.f;
     if (y <= H - 2) {
         const float* r0 = disp + (size_t)y * W;
         const float* r1 = r0 + W;
+        const float* rm = r0 - W;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int x = 4 * tq + j - MED_SKEW * l;
+            // plane 5: ORIGINAL value of (y-1, x+1).  Only lane 0 of the wave at the top of a band reads
+            // it (row 0 of the image is never modified; later bands overwrite it, see the serial kernel).
+            if (x + 1 >= 0 && x + 1 <= W - 1) e[5][j] = rm[x + 1];
             if (x < 0 || x > W - 1) continue;
             if (x == 0 || x == W - 1) { e[0][j] = r0[x]; continue; }          // border column: passed through
             float v0 = r0[x], v1 = r0[x + 1], v2 = r1[x - 1], v3 = r1[x], v4 = r1[x + 1];
@@ -912,11 +929,11 @@ __global__ __launch_bounds__(64) void sgm_median_prep_k(const float* __restrict_
         }
     }
 #pragma unroll
-    for (int k = 0; k < 5; ++k)
-        P[(((size_t)g * Tq + tq) * 5 + k) * 64 + l] = make_float4(e[k][0], e[k][1], e[k][2], e[k][3]);
+    for (int k = 0; k < MED_NE; ++k)
+        P[(((size_t)g * Tq + tq) * MED_NE + k) * 64 + l] = make_float4(e[k][0], e[k][1], e[k][2], e[k][3]);
 }
 
-__global__ __launch_bounds__(64 * MED_WAVES) void sgm_median_serial_k(float* __restrict__ disp, const float4* __restrict__ P,
+__global__ __launch_bounds__(64 * MED_WAVES) void sgm_median_serial_k(float* __restrict__ disp, float4* __restrict__ P,
                                                                       int W, int H, int Tq)
 {
     __shared__ __attribute__((aligned(16))) float ring[MED_WAVES][MED_RING];
@@ -926,10 +943,23 @@ __global__ __launch_bounds__(64 * MED_WAVES) void sgm_median_serial_k(float* __r
     const int rows = H - 2;
     if (rows <= 0 || W <= 2) return;
     const int groups = (rows + 63) / 64;
-    const int t_end = W + MED_LAG;                                   // lane 63 reaches column W-1 at t = W-1+MED_LAG
+    const int t_end = 4 * Tq;                                        // >= W + MED_LAG: lane 63 reaches column W-1 at t = W-1+MED_LAG
 
     for (int gbase = 0; gbase < groups; gbase += MED_WAVES) {
         if (threadIdx.x < MED_WAVES) { prog[threadIdx.x] = 0; cons[threadIdx.x] = 0; }
+        if (gbase > 0) {
+            // the row above this band is the previous band's finished last row: put it where lane 0 of the
+            // band's first wave expects the row above (plane 5), replacing the originals of the pre-pass
+            const float* const above = disp + (size_t)(64 * gbase) * W;
+            for (int tq = threadIdx.x; tq < Tq; tq += blockDim.x) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[j] = __hip_atomic_load(above + min(4 * tq + j + 1, W - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                P[(((size_t)gbase * Tq + tq) * MED_NE + 5) * 64] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            __threadfence();
+        }
         __syncthreads();
         const int g = gbase + wv;
         if (g < groups) {                                            // wave-uniform
@@ -940,29 +970,22 @@ __global__ __launch_bounds__(64 * MED_WAVES) void sgm_median_serial_k(float* __r
             const int yr = valid ? y : H - 2;
             float* const out_row = disp + (size_t)yr * W;
             const float* const top_row = disp + (size_t)(yr - 1) * W;
-            const float4* Pg = P + (size_t)g * Tq * 5 * 64 + l;
+            const float4* Pg = P + (size_t)g * Tq * MED_NE * 64 + l;
 
             float o1 = 0.f, o2 = 0.f;                                // own outputs of the last two steps
             float T0 = 0.f;                                          // out(y-1, x-1)
             float T1 = top_row[0];                                   // out(y-1, x): column 0 is border, never modified
-            // First wave of a band: the row above (image border row, or the finished last row of the
-            // previous band) is read 64 columns at a time, one chunk ahead; lane i of chunk k holds
-            // column 64k+1+i of the row above lane 0.
-            const float* const top0 = disp + (size_t)(64 * g) * W;   // row above this wave's lane 0
-            float chunk_cur = 0.f, chunk_nxt = 0.f;
-            if (!top_from_ring) chunk_nxt = __hip_atomic_load(top0 + min(1 + l, W - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
             // pre-sorted neighbourhoods are read-only input: keep MED_PF batches (4 steps each) in flight
-            float4 evr[MED_PF][5];
-            auto load_batch = [&](float4 (&dst)[5], int t0) {
+            float4 evr[MED_PF][MED_NE];
+            auto load_batch = [&](float4 (&dst)[MED_NE], int t0) {
                 const int tq = min(t0 >> 2, Tq - 1);
 #pragma unroll
-                for (int k = 0; k < 5; ++k) dst[k] = Pg[((size_t)tq * 5 + k) * 64];
+                for (int k = 0; k < MED_NE; ++k) dst[k] = Pg[((size_t)tq * MED_NE + k) * 64];
             };
 #pragma unroll
             for (int u = 0; u < MED_PF; ++u) load_batch(evr[u], 4 * u);
 
-            auto run_batch = [&](const float4 (&ev)[5], int t0) {
+            auto run_batch = [&](const float4 (&ev)[MED_NE], int t0) {
                 // ---- flow control between waves (LDS only) ----
                 if (top_from_ring) {
                     const int need = min(t0 + 4, W - 1);
@@ -982,13 +1005,8 @@ __global__ __launch_bounds__(64 * MED_WAVES) void sgm_median_serial_k(float* __r
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (l == 0) __hip_atomic_store(&cons[wv], t0 + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else {
-                    if ((t0 & 63) == 0) {
-                        chunk_cur = chunk_nxt;
-                        chunk_nxt = __hip_atomic_load(top0 + min(t0 + 64 + 1 + l, W - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        tv[j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(chunk_cur), (t0 & 63) + j));
+                    // top of a band: the row above comes with the pre-pass data (plane 5 of lane 0)
+                    tv[0] = ev[5].x; tv[1] = ev[5].y; tv[2] = ev[5].z; tv[3] = ev[5].w;
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -1022,10 +1040,8 @@ __global__ __launch_bounds__(64 * MED_WAVES) void sgm_median_serial_k(float* __r
 #pragma unroll
                 for (int u = 0; u < MED_PF; ++u) {
                     const int t0 = tb + 4 * u;
-                    if (t0 < t_end) {                                // wave-uniform
-                        run_batch(evr[u], t0);
-                        load_batch(evr[u], t0 + 4 * MED_PF);
-                    }
+                    run_batch(evr[u], t0);
+                    load_batch(evr[u], t0 + 4 * MED_PF);
                 }
             }
             if (l == 0) __hip_atomic_store(&cons[wv], 0x7FFFFFF0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1291,7 +1307,7 @@ size_t sgmd_median_scratch_bytes(const sgmd_geom* g)
 {
     const int groups = (g->H - 2 + 63) / 64;
     if (groups <= 0) return 16;
-    return (size_t)groups * med_tq(g->W) * 5 * 64 * sizeof(float4);
+    return (size_t)groups * med_tq(g->W) * MED_NE * 64 * sizeof(float4);
 }
 
 int sgmd_median(int ord, void* stream, const sgmd_geom* g, void* disp, void* scratch)
@@ -1305,7 +1321,7 @@ int sgmd_median(int ord, void* stream, const sgmd_geom* g, void* disp, void* scr
     hipLaunchKernelGGL(sgm_median_prep_k, dim3(Tq, groups), dim3(64), 0, st, (const float*)disp, (float4*)scratch, g->W,
                        g->H, Tq);
     const int waves = groups < MED_WAVES ? groups : MED_WAVES;
-    hipLaunchKernelGGL(sgm_median_serial_k, dim3(1), dim3(64 * waves), 0, st, (float*)disp, (const float4*)scratch, g->W,
+    hipLaunchKernelGGL(sgm_median_serial_k, dim3(1), dim3(64 * waves), 0, st, (float*)disp, (float4*)scratch, g->W,
                        g->H, Tq);
     HIP_TRY(hipGetLastError());
     return 0;
