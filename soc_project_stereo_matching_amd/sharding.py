@@ -1,0 +1,93 @@
+"""Frame-level sharding of a stereo stream over the GPUs of a node (one process per GPU).
+
+Frames are independent units of the hot path, so the data path needs no collective:
+rank r owns every frame whose index is congruent to r modulo the world size, matches them on its own
+GPU, and -- only if the caller wants the results in one place -- the disparity maps are gathered to
+rank 0 with torch.distributed.  `matcher` is any callable (left, right) -> float32 disparity: in the
+product it is an `SGMStream` over libsgm_mi355x.so; the CPU tests plug in the oracle to exercise
+this host logic with the gloo backend.
+"""
+from __future__ import annotations
+
+from typing import Callable, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+def frames_of_rank(n_frames: int, world: int, rank: int) -> List[int]:
+    """Round-robin assignment: frame i -> rank i % world (keeps a live stream balanced)."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad world/rank")
+    return list(range(rank, n_frames, world))
+
+
+def owner_of_frame(index: int, world: int) -> int:
+    return index % world
+
+
+class SGMStream:
+    """Round-robins frames of one rank over a few `SGMInstance`s (HIP streams) of its GPU so that
+    several frames are in flight; every frame is SGM_Reset + SGM_Match."""
+
+    def __init__(self, device: int, width: int, height: int, option, in_flight: int = 4):
+        from .sgm import SGMInstance
+        self.w, self.h, self.option = width, height, option
+        self.instances = [SGMInstance(device) for _ in range(max(1, in_flight))]
+        for inst in self.instances:
+            if not inst.reset(width, height, option):
+                raise RuntimeError("sgm_reset failed")
+        self._next = 0
+
+    def submit_device(self, d_left: int, d_right: int, d_out: int):
+        """Asynchronous: device pointers in, result lands in d_out after synchronize()."""
+        inst = self.instances[self._next % len(self.instances)]
+        self._next += 1
+        if not inst.reset(self.w, self.h, self.option):
+            raise RuntimeError("sgm_reset failed")
+        if not inst.match_device(d_left, d_right, d_out):
+            raise RuntimeError("sgm_match_device failed")
+        return inst
+
+    def __call__(self, left: np.ndarray, right: np.ndarray) -> np.ndarray:
+        inst = self.instances[self._next % len(self.instances)]
+        self._next += 1
+        if not inst.reset(self.w, self.h, self.option):
+            raise RuntimeError("sgm_reset failed")
+        out = inst.match(left, right)
+        if out is None:
+            raise RuntimeError("sgm_match failed")
+        return out
+
+    def synchronize(self):
+        for inst in self.instances:
+            if not inst.synchronize():
+                raise RuntimeError("sgm_synchronize failed")
+
+    def close(self):
+        for inst in self.instances:
+            inst.close()
+
+
+def match_sharded(frames: Sequence[Tuple[np.ndarray, np.ndarray]], matcher: Callable, world: int, rank: int,
+                  gather_to_rank0: bool = True, dist=None) -> Optional[List[np.ndarray]]:
+    """Match the frames this rank owns; optionally gather all disparity maps (in frame order) on rank 0.
+
+    `dist` is torch.distributed (already initialised) when world > 1.  Returns the full list on rank 0
+    (or the rank's own results when gather_to_rank0 is False), None on the other ranks."""
+    mine = frames_of_rank(len(frames), world, rank)
+    local = {i: matcher(frames[i][0], frames[i][1]) for i in mine}
+    if not gather_to_rank0:
+        return [local[i] for i in mine]
+    if world == 1:
+        return [local[i] for i in range(len(frames))]
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(local, gathered, dst=0)
+    if rank != 0:
+        return None
+    merged = {}
+    for part in gathered:
+        merged.update(part)
+    missing = [i for i in range(len(frames)) if i not in merged]
+    if missing:
+        raise RuntimeError(f"frames {missing} were not matched by any rank")
+    return [merged[i] for i in range(len(frames))]
