@@ -105,6 +105,14 @@ bool          sgm_synchronize(sgm_instance* s);
 /* The HIP stream (hipStream_t as void*) the instance launches on, e.g. to record events. */
 void*         sgm_stream(sgm_instance* s);
 
+/* Batches: after sgm_set_batch(s, n) and the next sgm_initialize / sgm_reset, every sgm_match /
+ * sgm_match_device call processes n frames of the same shape stored back to back ([n][H][W] for the
+ * images and the disparity output) -- each kernel of the pipeline covers all n frames in one launch,
+ * which is how one GPU is filled when frames are small.  n = 1 (default) is the reference behaviour. */
+bool          sgm_set_batch(sgm_instance* s, int frames);
+/* which frame of the batch sgm_read_stage returns (default 0) */
+void          sgm_select_frame(sgm_instance* s, int frame);
+
 /* ---- stage read-back (parity tests; copies device -> host, blocking) ----
  * which: 0 census left (u32 [H][W])       1 census right (u32 [H][W])
  *        2 matching cost (u8 [H][W][D])   3 aggregated cost S (u16 [H][W][D])
@@ -115,8 +123,10 @@ void*         sgm_stream(sgm_instance* s);
  * Returns the number of bytes written, 0 on error or if `capacity` is too small. */
 size_t sgm_read_stage(sgm_instance* s, int which, void* host_out, size_t capacity);
 size_t SGM_ReadStage(int which, void* host_out, size_t capacity);
-/* Stages 4, 6 and 7 are overwritten in place by the following stage; enable snapshots of them
- * (three extra device-to-device copies per match) before the match whose stages are read. */
+/* Stages 4, 6 and 7 are overwritten in place by the following stage and stage 2 (the cost volume) is
+ * normally never materialised (the aggregation kernel recomputes it from the census images); enable
+ * keeping them (one extra kernel + three device-to-device copies per match) before the match whose
+ * stages are read. */
 void   sgm_keep_stages(sgm_instance* s, int enable);
 void   SGM_KeepStages(int enable);
 

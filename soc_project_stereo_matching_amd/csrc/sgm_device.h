@@ -41,7 +41,10 @@ typedef struct {
     int D;             /* max_disparity - min_disparity */
     int Dp;            /* padded cell stride of the volumes: 16 * DPL >= D */
     int DPL;           /* disparities per lane in the aggregation kernel (2,4,8,12,16,32) */
+    int LPP;           /* lanes per pixel in the aggregation kernel: 16 (4 lines per wave) or 8 (8 lines); Dp = LPP*DPL */
     int dmin;          /* min_disparity */
+    int B;             /* frames per launch (batch): every buffer is [B][...] frame-major, every kernel
+                          processes all B frames */
 } sgmd_geom;
 
 /* one anomalous-line visit that lands on a pixel of row `row` (built by the host) */
@@ -68,10 +71,15 @@ int sgmd_census(int ord, void* stream, const sgmd_geom* g, const void* left, con
 int sgmd_cost(int ord, void* stream, const sgmd_geom* g, const void* census_l, const void* census_r, void* cost);
 
 /* All directions of the path aggregation in ONE launch.  SemiGlobalMatching.c:198-372.
+ * The matching cost (SemiGlobalMatching.c:161-196) is recomputed from the census images inside the
+ * kernel; census_r must be preceded by at least sgmd_census_slack(g) readable bytes (disparities that
+ * reach left of column 0 read there and are masked to 127).
  * planes: u8 [ndirs][H][W][Dp] per-direction path costs L_r; extras: u8 [4][H][Dp] path costs of
  * the four anomalous diagonal lines (step-major); lut: u16[256] = (uint16)max(P1, P2/(a+1)). */
+size_t sgmd_census_slack(const sgmd_geom* g);
 int sgmd_aggregate(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* paths, const void* img_left,
-                   const void* cost, const void* lut, void* planes, size_t plane_bytes, void* extras);
+                   const void* census_l, const void* census_r, const void* lut, void* planes, size_t plane_bytes,
+                   void* extras);
 
 /* S = (accumulate ? S : 0) + sum of planes + anomalous-line visits.  u16 [H][W][Dp] */
 int sgmd_sum(int ord, void* stream, const sgmd_geom* g, int ndirs, const void* planes, size_t plane_bytes,

@@ -19,6 +19,7 @@
 #include <string.h>
 
 #define SGM_VERSION_STRING "sgm_mi355x 0.1 (gfx950, hand-written HIP)"
+#define CENSUS_FRONT_SLACK ((size_t)(65535 + SGM_MAX_DISPARITY_RANGE + 8 + 63) / 64 * 64 * 4)   /* >= sgmd_census_slack() for any options */
 
 enum { T_CENSUS, T_COST, T_AGGREGATE, T_SUM, T_WTA, T_LRCHECK, T_SPECKLE, T_MEDIAN, T_COUNT };
 static const char* const k_stage_names[T_COUNT] = {"census", "cost", "aggregate", "sum", "wta", "lrcheck", "speckle", "median"};
@@ -34,6 +35,8 @@ struct sgm_instance {
     int timing;
     int keep_stages;
     int honor_num_paths;
+    int batch;                   /* frames per match call (>= 1); takes effect at the next initialize */
+    int read_frame;              /* which frame of the batch sgm_read_stage returns */
 
     bool initialized;
     bool s_is_zero;              /* aggregated-cost volume logically zero (set by Initialize/Reset, Q14) */
@@ -49,7 +52,7 @@ struct sgm_instance {
     size_t cap_px, cap_cells, cap_extras, cap_median;
     int cap_H, cap_row_cap;
     int tab_W, tab_H, tab_ndirs, tab_p1, tab_p2;   /* what the uploaded tables were built for */
-    void *d_left, *d_right, *d_census_l, *d_census_r, *d_cost, *d_planes, *d_extras, *d_S;
+    void *d_left, *d_right, *d_census_l, *d_census_r, *d_census_r_alloc, *d_cost, *d_planes, *d_extras, *d_S;
     void *d_disp, *d_disp_r, *d_labels, *d_sizes, *d_lut, *d_row_extras, *d_row_count;
     void *d_snap_wta, *d_snap_lr, *d_snap_speckle, *d_totals, *d_median_scratch;
     size_t plane_bytes;
@@ -143,13 +146,15 @@ sgm_instance* sgm_create(int device)
     sgm_instance* s = (sgm_instance*)calloc(1, sizeof *s);
     if (!s) return NULL;
     s->device = device;
+    s->batch = 1;
     if (sgmd_stream_create(device, &s->stream) != 0) { free(s); return NULL; }
     return s;
 }
 
 static void free_device_buffers(sgm_instance* s)
 {
-    void** all[] = {&s->d_left, &s->d_right, &s->d_census_l, &s->d_census_r, &s->d_cost, &s->d_planes, &s->d_extras,
+    s->d_census_r = NULL;                                        /* points into d_census_r_alloc */
+    void** all[] = {&s->d_left, &s->d_right, &s->d_census_l, &s->d_census_r_alloc, &s->d_cost, &s->d_planes, &s->d_extras,
                     &s->d_S, &s->d_disp, &s->d_disp_r, &s->d_labels, &s->d_sizes, &s->d_lut, &s->d_row_extras,
                     &s->d_row_count, &s->d_snap_wta, &s->d_snap_lr, &s->d_snap_speckle, &s->d_totals,
                     &s->d_median_scratch};
@@ -178,6 +183,19 @@ void sgm_destroy(sgm_instance* s)
 
 void sgm_set_honor_num_paths(sgm_instance* s, int honor) { if (s) s->honor_num_paths = honor; }
 void sgm_keep_stages(sgm_instance* s, int enable) { if (s) s->keep_stages = enable; }
+
+bool sgm_set_batch(sgm_instance* s, int frames)
+{
+    if (!s || frames < 1 || frames > 1024) return false;
+    if (frames != s->batch) s->initialized = false;              /* buffers are sized at the next initialize */
+    s->batch = frames;
+    return true;
+}
+
+void sgm_select_frame(sgm_instance* s, int frame)
+{
+    if (s && frame >= 0 && frame < s->batch) s->read_frame = frame;
+}
 void* sgm_stream(sgm_instance* s) { return s ? s->stream : NULL; }
 
 void sgm_enable_timing(sgm_instance* s, int enable)
@@ -258,7 +276,7 @@ static bool upload_tables(sgm_instance* s)
 
 static bool ensure_buffers(sgm_instance* s)
 {
-    const size_t px = (size_t)s->g.W * s->g.H;
+    const size_t px = (size_t)s->g.B * s->g.W * s->g.H;          /* all frames of the batch, frame-major */
     const size_t cells = px * (size_t)s->g.Dp;
     if (px <= s->cap_px && cells <= s->cap_cells && s->d_S) return true;
     sgmd_stream_sync(s->device, s->stream);
@@ -268,7 +286,10 @@ static bool ensure_buffers(sgm_instance* s)
     rc |= sgmd_alloc(dev, &s->d_left, px);
     rc |= sgmd_alloc(dev, &s->d_right, px);
     rc |= sgmd_alloc(dev, &s->d_census_l, px * 4);
-    rc |= sgmd_alloc(dev, &s->d_census_r, px * 4);
+    /* the aggregation kernel reads census-right up to dmin + Dp - 1 words left of a row start (masked to 127
+     * afterwards); give the buffer that much readable slack in front, sized for the largest options */
+    rc |= sgmd_alloc(dev, &s->d_census_r_alloc, CENSUS_FRONT_SLACK + px * 4);
+    if (rc == 0) s->d_census_r = (char*)s->d_census_r_alloc + CENSUS_FRONT_SLACK;
     rc |= sgmd_alloc(dev, &s->d_cost, cells);
     rc |= sgmd_alloc(dev, &s->d_planes, cells * 8);
     rc |= sgmd_alloc(dev, &s->d_S, cells * 2);
@@ -303,8 +324,18 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
 
     s->g.W = width; s->g.H = height; s->g.D = D;
     s->g.DPL = pick_dpl(D);
+    s->g.LPP = 16;
     s->g.Dp = 16 * s->g.DPL;
+    /* a batch of frames is VALU-bound: 8 lanes per pixel (twice the disparities per lane, same Dp) spends
+     * fewer instructions per cell; a single frame keeps 16 lanes per pixel for the shorter serial step */
+    {
+        const char* e = getenv("SGM_LANES_PER_PIXEL");
+        const int want = (e && *e) ? atoi(e) : (s->batch >= 2 ? 8 : 16);
+        if (want == 8 && s->g.DPL >= 2 && s->g.DPL <= 8 && s->g.DPL != 6) { s->g.LPP = 8; s->g.DPL *= 2; }
+    }
     s->g.dmin = option->min_disparity;
+    s->g.B = s->batch;
+    if (s->read_frame >= s->batch) s->read_frame = 0;
     if ((unsigned long long)width * height * (unsigned)s->g.Dp >= 0xFFFFFFFFull)
         FAIL("cost volume too large: width*height*%d must stay below 2^32 cells (32-bit offsets in the kernels)", s->g.Dp);
 
@@ -320,7 +351,7 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
 
     if (!ensure_buffers(s)) return false;
     /* extras: 4 anomalous lines x H steps x Dp bytes */
-    const size_t extras_bytes = (size_t)4 * height * s->g.Dp;
+    const size_t extras_bytes = (size_t)s->g.B * 4 * height * s->g.Dp;
     if (extras_bytes > s->cap_extras || !s->d_extras) {
         sgmd_stream_sync(s->device, s->stream);
         sgmd_free(s->device, s->d_extras);
@@ -371,17 +402,20 @@ static bool run_pipeline(sgm_instance* s, const void* d_left, const void* d_righ
     void* st = s->stream;
     const sgmd_geom* g = &s->g;
     const SGMOption* o = &s->opt;
-    const size_t px_bytes = (size_t)g->W * g->H * sizeof(float);
+    const size_t px_bytes = (size_t)g->B * g->W * g->H * sizeof(float);
     int rc = 0;
 
     mark(s, 0);
     rc |= sgmd_census(dev, st, g, d_left, d_right, s->d_census_l, s->d_census_r);              /* .c:82-83 */
     mark(s, 1);
-    rc |= sgmd_cost(dev, st, g, s->d_census_l, s->d_census_r, s->d_cost);                       /* .c:89 */
+    /* .c:89: the cost volume is recomputed inside the aggregation kernel; it is only materialised when a
+     * test wants to read it back (stage 2) */
+    if (s->keep_stages) rc |= sgmd_cost(dev, st, g, s->d_census_l, s->d_census_r, s->d_cost);
     mark(s, 2);
     if (s->need_plane_memset && s->paths.ndirs > 4)
-        rc |= sgmd_memset_async(dev, st, (char*)s->d_planes + 4 * s->plane_bytes, 0, 4 * s->plane_bytes);
-    rc |= sgmd_aggregate(dev, st, g, &s->paths, d_left, s->d_cost, s->d_lut, s->d_planes, s->plane_bytes,
+        for (int f = 0; f < g->B; ++f)
+            rc |= sgmd_memset_async(dev, st, (char*)s->d_planes + ((size_t)f * 8 + 4) * s->plane_bytes, 0, 4 * s->plane_bytes);
+    rc |= sgmd_aggregate(dev, st, g, &s->paths, d_left, s->d_census_l, s->d_census_r, s->d_lut, s->d_planes, s->plane_bytes,
                          s->d_extras);                                                          /* .c:94 */
     mark(s, 3);
     rc |= sgmd_sum(dev, st, g, s->paths.ndirs, s->d_planes, s->plane_bytes, s->d_extras, s->d_row_extras,
@@ -434,7 +468,7 @@ bool sgm_match(sgm_instance* s, const uint8_t* img_left, const uint8_t* img_righ
     if (!s || !s->initialized) return false;                     /* .c:70 */
     if (!img_left || !img_right) return false;                   /* .c:73 */
     if (!disp_left) return false;
-    const size_t px = (size_t)s->g.W * s->g.H;
+    const size_t px = (size_t)s->g.B * s->g.W * s->g.H;           /* batch > 1: B consecutive frames */
     memcpy(s->h_left, img_left, px);
     memcpy(s->h_right, img_right, px);
     if (sgmd_h2d_async(s->device, s->stream, s->d_left, s->h_left, px) != 0) return false;
@@ -461,28 +495,29 @@ static size_t compact_volume(const sgm_instance* s, const void* padded, size_t e
 size_t sgm_read_stage(sgm_instance* s, int which, void* host_out, size_t capacity)
 {
     if (!s || !s->initialized || !host_out) return 0;
-    const size_t px = (size_t)s->g.W * s->g.H;
-    const void* src = NULL;
+    const size_t px = (size_t)s->g.W * s->g.H;                    /* one frame */
+    const size_t f = (size_t)s->read_frame;
+    const char* src = NULL;
     size_t elem = 0;
     bool volume = false;
     switch (which) {
-    case 0: src = s->d_census_l; elem = 4; break;
-    case 1: src = s->d_census_r; elem = 4; break;
-    case 2: src = s->d_cost; elem = 1; volume = true; break;
-    case 3: src = s->d_S; elem = 2; volume = true; break;
-    case 4: src = s->d_snap_wta; elem = 4; break;
-    case 5: src = s->d_disp_r; elem = 4; break;
-    case 6: src = s->d_snap_lr; elem = 4; break;
-    case 7: src = s->d_snap_speckle; elem = 4; break;
-    case 8: src = s->d_disp; elem = 4; break;
+    case 0: src = (const char*)s->d_census_l + f * px * 4; elem = 4; break;
+    case 1: src = (const char*)s->d_census_r + f * px * 4; elem = 4; break;
+    case 2: src = (const char*)s->d_cost + f * px * s->g.Dp; elem = 1; volume = true; break;
+    case 3: src = (const char*)s->d_S + f * px * s->g.Dp * 2; elem = 2; volume = true; break;
+    case 4: src = (const char*)s->d_snap_wta + f * px * 4; elem = 4; break;
+    case 5: src = (const char*)s->d_disp_r + f * px * 4; elem = 4; break;
+    case 6: src = (const char*)s->d_snap_lr + f * px * 4; elem = 4; break;
+    case 7: src = (const char*)s->d_snap_speckle + f * px * 4; elem = 4; break;
+    case 8: src = (const char*)s->d_disp + f * px * 4; elem = 4; break;
     default:
         if (which >= 10 && which < 10 + s->paths.ndirs) {
-            src = (const char*)s->d_planes + (size_t)(which - 10) * s->plane_bytes;
+            src = (const char*)s->d_planes + (f * 8 + (size_t)(which - 10)) * s->plane_bytes;
             elem = 1; volume = true;
         }
     }
     if (!src) return 0;
-    if ((which == 4 || which == 6 || which == 7) && !s->keep_stages) return 0;
+    if ((which == 2 || which == 4 || which == 6 || which == 7) && !s->keep_stages) return 0;
     const size_t need = volume ? px * s->g.D * elem : px * elem;
     if (capacity < need) return 0;
     if (sgmd_stream_sync(s->device, s->stream) != 0) return 0;

@@ -63,12 +63,13 @@ static __device__ __forceinline__ unsigned dpp_perm(unsigned src)
 {
     return (unsigned)__builtin_amdgcn_mov_dpp((int)src, CTRL, 0xF, 0xF, true);
 }
+template <int LPP = 16>
 static __device__ __forceinline__ unsigned row_allmin(unsigned v)
 {
     v = min(v, dpp_perm<DPP_QUAD_XOR1>(v));
     v = min(v, dpp_perm<DPP_QUAD_XOR2>(v));
-    v = min(v, dpp_perm<DPP_ROW_HALF_MIRROR>(v));
-    v = min(v, dpp_perm<DPP_ROW_MIRROR>(v));
+    v = min(v, dpp_perm<DPP_ROW_HALF_MIRROR>(v));                 // all 8 lanes of a half row agree
+    if (LPP == 16) v = min(v, dpp_perm<DPP_ROW_MIRROR>(v));       // all 16 lanes of the row agree
     return v;
 }
 
@@ -82,8 +83,9 @@ __global__ __launch_bounds__(256) void sgm_census_k(const uint8_t* __restrict__ 
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
-    const uint8_t* img = blockIdx.z ? right : left;
-    uint32_t* out = blockIdx.z ? cr : cl;
+    const size_t frame_px = (size_t)(blockIdx.z >> 1) * W * H;         // batch: z = 2 * frame + image
+    const uint8_t* img = ((blockIdx.z & 1) ? right : left) + frame_px;
+    uint32_t* out = ((blockIdx.z & 1) ? cr : cl) + frame_px;
     uint32_t bits = 0;
     // border of 2 px is never written by the reference (zero-initialised statics, Q3); also nothing
     // at all is written for images with W <= 5 or H <= 5 (ref :136)
@@ -108,6 +110,9 @@ __global__ __launch_bounds__(256) void sgm_cost_k(const uint32_t* __restrict__ c
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long total = (long long)W * H * chunks;
     if (t >= total) return;
+    cl += (size_t)blockIdx.y * W * H;                                  // batch: y = frame
+    cr += (size_t)blockIdx.y * W * H;
+    cost += (size_t)blockIdx.y * W * H * Dp;
     const int chunk = (int)(t % chunks);
     const long long pix = t / chunks;
     const int x = (int)(pix % W);
@@ -145,18 +150,31 @@ __global__ __launch_bounds__(256) void sgm_cost_k(const uint32_t* __restrict__ c
 
 struct AggArgs {
     const uint8_t* img;
-    const uint8_t* cost;
+    const uint32_t* census_l;
+    const uint32_t* census_r;   // the allocation has >= dmin + Dp dwords of slack in front (reads left of column 0)
+    int dmin;
     const uint16_t* lut;        // (uint16) max(P1, P2 / (|dg| + 1)), 256 entries (ref :335)
     uint8_t* planes;
     size_t plane_bytes;
     uint8_t* extras;
     int W, H, D, Dp;
+    int B;                      // frames per launch; frame f uses img/census + f*W*H, planes + f*8*plane_bytes, extras + f*4*H*Dp
     int p1;
     int ndirs;
     int dx[8], dy[8];
     int anom_line[8];
     int block_begin[9];
     int ghost_zero;
+};
+
+// per-frame base pointers of a batched launch (kept apart from the kernel-argument struct so that struct
+// stays in the scalar kernarg segment)
+struct AggFrame {
+    const uint8_t* img;
+    const uint32_t* census_l;
+    const uint32_t* census_r;
+    uint8_t* planes;
+    uint8_t* extras;
 };
 
 template <int DPL> struct CellVec { unsigned w[(DPL + 3) / 4]; };
@@ -238,22 +256,70 @@ static __device__ __forceinline__ void pack_cells(const us2 (&pr)[DPL / 2], Cell
     }
 }
 
+// The matching cost is recomputed here from the two census images instead of being read from a
+// materialised cost volume: C(p,d) = popcount(cl[y][x] ^ cr[y][x-d]), 127 where x-d is left of the image
+// (ref :161-196).  The census images (2 x 1.9 MB at KITTI) stay in L2, so the 8 directions no longer
+// stream the 60 MB volume from HBM eight times.
+//
+// CensusVec holds, for the DPL disparities of a lane, the census-right words in ASCENDING ADDRESS order:
+// r[j] = cr[y][x - dmin - lane_off - (DPL-1) + j], i.e. r[DPL-1-i] belongs to the lane's i-th disparity.
+template <int DPL> struct CensusVec { unsigned r[DPL]; };
+
+template <int DPL>
+static __device__ __forceinline__ void load_census(const uint32_t* p, CensusVec<DPL>& v)
+{
+    if constexpr (DPL == 2) {
+        struct __attribute__((packed, aligned(4))) u2 { unsigned a, b; };
+        const u2 t = *reinterpret_cast<const u2*>(p);
+        v.r[0] = t.a; v.r[1] = t.b;
+    } else {
+        struct __attribute__((packed, aligned(4))) u4 { unsigned a, b, c, d; };
+#pragma unroll
+        for (int q = 0; q < DPL / 4; ++q) {
+            const u4 t = *reinterpret_cast<const u4*>(p + 4 * q);
+            v.r[4 * q] = t.a; v.r[4 * q + 1] = t.b; v.r[4 * q + 2] = t.c; v.r[4 * q + 3] = t.d;
+        }
+    }
+}
+
+// packed u16 cost pairs of a lane.  `lim` = x - dmin - lane_off: disparity i of the lane is inside the
+// image iff i <= lim; `masked` (wave-uniform) says whether any lane of the wave needs the test at all.
+template <int DPL>
+static __device__ __forceinline__ void census_costs(unsigned cl, const CensusVec<DPL>& cv, int lim, bool masked,
+                                                    us2 (&C)[DPL / 2])
+{
+#pragma unroll
+    for (int j = 0; j < DPL / 2; ++j) {
+        const unsigned hi = (unsigned)__popc(cl ^ cv.r[DPL - 2 - 2 * j]) << 16;
+        C[j] = as_p((unsigned)__popc(cl ^ cv.r[DPL - 1 - 2 * j]) + hi);
+    }
+    if (masked) {
+#pragma unroll
+        for (int j = 0; j < DPL / 2; ++j) {
+            const unsigned m = (2 * j > lim ? 0xFFFFu : 0u) | (2 * j + 1 > lim ? 0xFFFF0000u : 0u);
+            C[j] = as_p((as_u(C[j]) & ~m) | (0x007F007Fu & m));           // UINT8_MAX/2 (ref :170-171)
+        }
+    }
+}
+
 // One aggregation step for the 4 lines of a wave: returns the new packed L_r in Ln and the new
 // row minimum; Lp/min_prev are the previous pixel's (ref :329-353).
-template <int DPL, bool PAD>
-static __device__ __forceinline__ unsigned agg_step(const CellVec<DPL>& cells, us2 (&Lp)[DPL / 2], unsigned min_prev,
+template <int DPL, bool PAD, int LPP>
+static __device__ __forceinline__ unsigned agg_step(const us2 (&C)[DPL / 2], us2 (&Lp)[DPL / 2], unsigned min_prev,
                                                     unsigned pen16, us2 p1v, const us2 (&padmask)[DPL / 2],
-                                                    CellVec<DPL>& packed_out)
+                                                    bool first_lane, bool last_lane, CellVec<DPL>& packed_out)
 {
     constexpr int NP = DPL / 2;
-    us2 C[NP];
-    unpack_cells<DPL>(cells, C);
     const unsigned l4u = (min_prev + pen16) & 0xFFFFu;                     // ref :335, truncated to u16
     const us2 l4 = as_p(l4u | (l4u << 16));
     const us2 mp = as_p(min_prev | (min_prev << 16));
     // d-1 / d+1 neighbours across the lane boundary; 255 where there is none (ref :260-263)
-    const unsigned from_left = dpp_mov<DPP_ROW_SHR1>(0x00FF00FFu, as_u(Lp[NP - 1]));
-    const unsigned from_right = dpp_mov<DPP_ROW_SHL1>(0x00FF00FFu, as_u(Lp[0]));
+    unsigned from_left = dpp_mov<DPP_ROW_SHR1>(0x00FF00FFu, as_u(Lp[NP - 1]));
+    unsigned from_right = dpp_mov<DPP_ROW_SHL1>(0x00FF00FFu, as_u(Lp[0]));
+    if (LPP == 8) {                                     // two pixels share a 16-lane DPP row: cut the shift between them
+        from_left = first_lane ? 0x00FF00FFu : from_left;
+        from_right = last_lane ? 0x00FF00FFu : from_right;
+    }
     us2 Ln[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
@@ -275,7 +341,7 @@ static __device__ __forceinline__ unsigned agg_step(const CellVec<DPL>& cells, u
 #pragma unroll
     for (int j = 0; j < NP; ++j) Lp[j] = Ln[j];
     pack_cells<DPL>(Ln, packed_out);
-    return row_allmin(min(as_u(m) & 0xFFFFu, as_u(m) >> 16));             // ref :347,353
+    return row_allmin<LPP>(min(as_u(m) & 0xFFFFu, as_u(m) >> 16));        // ref :347,353
 }
 
 enum { AGG_H = 0, AGG_V = 1, AGG_D = 2 };
@@ -284,12 +350,12 @@ enum { AGG_H = 0, AGG_V = 1, AGG_D = 2 };
 // (the host guarantees W*H*Dp < 2^32); the walk is the reference's (ref :281-323, 359-367) with the
 // row test dropped (a regular line is never in the last row before its final step) and the two
 // edge tests turned into selects.
-template <int DPL, bool PAD, int KIND>
-static __device__ __forceinline__ void agg_regular(const AggArgs& a, const unsigned short* lut_s, int dir, int grp)
+template <int DPL, bool PAD, int LPP, int KIND>
+static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFrame& fr, const unsigned short* lut_s,
+                                                   int dir, int grp)
 {
     constexpr int NP = DPL / 2;
-    constexpr int NW = (DPL + 3) / 4;
-    constexpr int PF = 4;                                                  // software prefetch depth (steps)
+    constexpr int PF = 2;                                                  // software prefetch depth (steps); 2 keeps DPL=8 at 56 VGPRs = 8 waves/SIMD
     const int lane = threadIdx.x;
     const int dx = a.dx[dir], dy = a.dy[dir];
     const int W = a.W, H = a.H, Dp = a.Dp;
@@ -299,8 +365,10 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const unsig
     const int nsteps = ((KIND == AGG_H) ? W : H) - 1;                      // ref :281
     if (KIND == AGG_D && W < 2) return;                                    // the only line is the anomalous one
 
-    const int sub = lane & 15;
-    int line = grp * 4 + (lane >> 4);
+    constexpr int LPW = 64 / LPP;                                          // path lines per wave
+    const int sub = lane & (LPP - 1);
+    const bool first_lane = (sub == 0), last_lane = (sub == LPP - 1);
+    int line = grp * LPW + lane / LPP;
     bool store_ok = line < nlines;
     if (!store_ok) line = nlines - 1;                                      // keep the wave convergent; stores are masked
     if (KIND == AGG_D && line == a.anom_line[dir]) {                       // handled by agg_anomalous()
@@ -308,7 +376,7 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const unsig
         line = (line == 0) ? 1 : line - 1;
     }
     const unsigned lane_off = (unsigned)(sub * DPL);
-    uint8_t* const plane = a.planes + (size_t)dir * a.plane_bytes;
+    uint8_t* const plane = fr.planes + (size_t)dir * a.plane_bytes;
 
     us2 padmask[NP];
 #pragma unroll
@@ -318,28 +386,39 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const unsig
         padmask[j] = as_p(lo | hi);
     }
 
-    // fetch cursor: pixel index p (grey value) and byte offset of this lane's cells
+    // fetch cursor: pixel index p (grey value, census), true column x and byte offset of this lane's cells
     unsigned p, off;
+    int x;
     unsigned rowpix = 0, rowoff = 0, pcol = 0, col = 0;                    // AGG_D only
     int dstep_p = 0, dstep_off = 0;
     if (KIND == AGG_H) {
-        p = (unsigned)(line * W + (fwd ? 0 : W - 1));
+        x = fwd ? 0 : W - 1;
+        p = (unsigned)(line * W + x);
         dstep_p = s; dstep_off = s * Dp;
     } else if (KIND == AGG_V) {
+        x = line;
         p = (unsigned)((fwd ? 0 : (H - 1) * W) + line);
         dstep_p = s * W; dstep_off = s * W * Dp;
     } else {
         rowpix = (unsigned)(fwd ? 0 : (H - 1) * W);
         rowoff = rowpix * (unsigned)Dp;
         pcol = col = (unsigned)line;
+        x = line;
         p = rowpix + pcol;
         dstep_p = s * W; dstep_off = s * W * Dp;
     }
     off = p * (unsigned)Dp + lane_off;
     const int col_step = (dx == dy) ? s : -s;                              // ref :360-367
+    // census-right words of this lane's disparities start (ascending addresses) at pixel p - back
+    const int back = a.dmin + (int)lane_off + DPL - 1;
+    const int lim_bias = a.dmin + (int)lane_off;                           // disparity i of the lane is in the image iff i <= x - lim_bias
 
     auto advance = [&]() {
-        if (KIND != AGG_D) {
+        if (KIND == AGG_H) {
+            p += (unsigned)dstep_p;
+            off += (unsigned)dstep_off;
+            x += s;
+        } else if (KIND == AGG_V) {
             p += (unsigned)dstep_p;
             off += (unsigned)dstep_off;
         } else {
@@ -350,8 +429,14 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const unsig
             rowpix += (unsigned)dstep_p;
             rowoff += (unsigned)dstep_off;
             p = rowpix + pcol;
+            x = (int)pcol;
             off = rowoff + __umul24(pcol, (unsigned)Dp) + lane_off;
         }
+    };
+    auto fetch = [&](CensusVec<DPL>& cv, unsigned& cl, int& g) {
+        load_census<DPL>(fr.census_r + ((long long)p - back), cv);
+        cl = fr.census_l[p];
+        g = fr.img[p];
     };
 
     // ---- first pixel of the line: L = C (ref :266-275) ----
@@ -359,10 +444,11 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const unsig
     unsigned min_prev;
     int g_prev;
     {
-        CellVec<DPL> c0;
-        load_cells<DPL>(a.cost + off, c0);
-        g_prev = a.img[p];
-        unpack_cells<DPL>(c0, Lp);
+        CensusVec<DPL> cv;
+        unsigned cl;
+        fetch(cv, cl, g_prev);
+        const int lim = x - lim_bias;
+        census_costs<DPL>(cl, cv, lim, true, Lp);
         if (PAD) {
 #pragma unroll
             for (int j = 0; j < NP; ++j) Lp[j] = as_p(as_u(Lp[j]) | as_u(padmask[j]));
@@ -370,7 +456,7 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const unsig
         us2 m = Lp[0];
 #pragma unroll
         for (int j = 1; j < NP; ++j) m = pk_min(m, Lp[j]);
-        min_prev = row_allmin(min(as_u(m) & 0xFFFFu, as_u(m) >> 16));
+        min_prev = row_allmin<LPP>(min(as_u(m) & 0xFFFFu, as_u(m) >> 16));
         if (store_ok) {
             CellVec<DPL> o;
             pack_cells<DPL>(Lp, o);
@@ -378,38 +464,41 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const unsig
         }
     }
 
-    // ---- prefetch ring ----
-    CellVec<DPL> cb[PF];
-    int gb[PF];
+    // ---- prefetch ring: census-right words, census-left word, grey value, offset, in-image limit ----
+    CensusVec<DPL> cb[PF];
+    unsigned clb[PF];
+    int gb[PF], limb[PF];
     unsigned ob[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-        gb[u] = 0; ob[u] = off;
+        gb[u] = 0; ob[u] = off; clb[u] = 0; limb[u] = 0;
 #pragma unroll
-        for (int i = 0; i < NW; ++i) cb[u].w[i] = 0;
+        for (int i = 0; i < DPL; ++i) cb[u].r[i] = 0;
         if (1 + u <= nsteps) {
             advance();
             ob[u] = off;
-            load_cells<DPL>(a.cost + off, cb[u]);
-            gb[u] = a.img[p];
+            limb[u] = x - lim_bias;
+            fetch(cb[u], clb[u], gb[u]);
         }
     }
     const us2 p1v = splat((unsigned)a.p1);
 
     // one step on ring slot u; `refill` = also fetch step k + PF into the slot
     auto step = [&](int u, bool refill) {
-        const CellVec<DPL> cells = cb[u];
         const int g = gb[u];
+        const int lim = limb[u];
         const unsigned o = ob[u];
+        us2 C[NP];
+        census_costs<DPL>(clb[u], cb[u], lim, __any(lim < DPL - 1) != 0, C);   // consume the slot, then refill it
         if (refill) {
             advance();
             ob[u] = off;
-            load_cells<DPL>(a.cost + off, cb[u]);
-            gb[u] = a.img[p];
+            limb[u] = x - lim_bias;
+            fetch(cb[u], clb[u], gb[u]);
         }
         const int dg = g > g_prev ? g - g_prev : g_prev - g;
         CellVec<DPL> packed;
-        min_prev = agg_step<DPL, PAD>(cells, Lp, min_prev, lut_s[dg], p1v, padmask, packed);
+        min_prev = agg_step<DPL, PAD, LPP>(C, Lp, min_prev, lut_s[dg], p1v, padmask, first_lane, last_lane, packed);
         g_prev = g;
         if (store_ok) store_cells<DPL>(plane + o, packed);
     };
@@ -432,8 +521,9 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const unsig
 // also visited by regular lines), and it zeroes the cells no line visits (W >= H: the track it
 // should have taken).  One wave per diagonal direction; all four DPP rows compute the same line,
 // row 0 stores.
-template <int DPL, bool PAD>
-static __device__ __forceinline__ void agg_anomalous(const AggArgs& a, const unsigned short* lut_s, int dir)
+template <int DPL, bool PAD, int LPP>
+static __device__ __forceinline__ void agg_anomalous(const AggArgs& a, const AggFrame& fr, const unsigned short* lut_s,
+                                                     int dir)
 {
     constexpr int NP = DPL / 2;
     constexpr int NW = (DPL + 3) / 4;
@@ -448,10 +538,12 @@ static __device__ __forceinline__ void agg_anomalous(const AggArgs& a, const uns
     const long long npx = (long long)W * H;
     const int line = a.anom_line[dir];
     const int slot = dir - 4;
-    const bool store_ok = lane < 16;
-    const unsigned lane_off = (unsigned)((lane & 15) * DPL);
-    uint8_t* const plane = a.planes + (size_t)dir * a.plane_bytes;
-    uint8_t* const extras = a.extras + (size_t)slot * H * Dp + lane_off;
+    const bool store_ok = lane < LPP;
+    const int sub = lane & (LPP - 1);
+    const bool first_lane = (sub == 0), last_lane = (sub == LPP - 1);
+    const unsigned lane_off = (unsigned)(sub * DPL);
+    uint8_t* const plane = fr.planes + (size_t)dir * a.plane_bytes;
+    uint8_t* const extras = fr.extras + (size_t)slot * H * Dp + lane_off;
 
     us2 padmask[NP];
 #pragma unroll
@@ -478,11 +570,13 @@ static __device__ __forceinline__ void agg_anomalous(const AggArgs& a, const uns
     us2 Lp[NP];
     unsigned min_prev;
     int g_prev;
+    const int back = a.dmin + (int)lane_off + DPL - 1;
+    const int lim_bias = a.dmin + (int)lane_off;
     {
-        CellVec<DPL> c0;
-        load_cells<DPL>(a.cost + (size_t)p * Dp + lane_off, c0);
-        g_prev = a.img[p];
-        unpack_cells<DPL>(c0, Lp);
+        CensusVec<DPL> cv;
+        load_census<DPL>(fr.census_r + (p - back), cv);
+        g_prev = fr.img[p];
+        census_costs<DPL>(fr.census_l[p], cv, (int)(p % W) - lim_bias, true, Lp);
         if (PAD) {
 #pragma unroll
             for (int j = 0; j < NP; ++j) Lp[j] = as_p(as_u(Lp[j]) | as_u(padmask[j]));
@@ -490,7 +584,7 @@ static __device__ __forceinline__ void agg_anomalous(const AggArgs& a, const uns
         us2 m = Lp[0];
 #pragma unroll
         for (int j = 1; j < NP; ++j) m = pk_min(m, Lp[j]);
-        min_prev = row_allmin(min(as_u(m) & 0xFFFFu, as_u(m) >> 16));
+        min_prev = row_allmin<LPP>(min(as_u(m) & 0xFFFFu, as_u(m) >> 16));
         if (store_ok) {
             CellVec<DPL> o;
             pack_cells<DPL>(Lp, o);
@@ -511,11 +605,14 @@ static __device__ __forceinline__ void agg_anomalous(const AggArgs& a, const uns
             if (p < 0 || p >= npx) dead = true;                            // Q6: the line ends
         }
         if (!dead) {                                                       // uniform (all rows walk the same line)
-            CellVec<DPL> cells, packed;
-            load_cells<DPL>(a.cost + (size_t)p * Dp + lane_off, cells);
-            const int g = a.img[p];
+            CellVec<DPL> packed;
+            CensusVec<DPL> cv;
+            us2 C[NP];
+            load_census<DPL>(fr.census_r + (p - back), cv);
+            const int g = fr.img[p];
+            census_costs<DPL>(fr.census_l[p], cv, (int)(p % W) - lim_bias, true, C);
             const int dg = g > g_prev ? g - g_prev : g_prev - g;
-            min_prev = agg_step<DPL, PAD>(cells, Lp, min_prev, lut_s[dg], p1v, padmask, packed);
+            min_prev = agg_step<DPL, PAD, LPP>(C, Lp, min_prev, lut_s[dg], p1v, padmask, first_lane, last_lane, packed);
             g_prev = g;
             if (store_ok) store_cells<DPL>(extras + (size_t)k * Dp, packed);
         }
@@ -523,7 +620,7 @@ static __device__ __forceinline__ void agg_anomalous(const AggArgs& a, const uns
     }
 }
 
-template <int DPL, bool PAD>
+template <int DPL, bool PAD, int LPP>
 __global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
 {
     __shared__ unsigned short lut_s[256];
@@ -532,19 +629,30 @@ __global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
     for (int i = 0; i < 4; ++i) lut_s[lane * 4 + i] = a.lut[lane * 4 + i];
     __syncthreads();
 
-    // blocks [block_begin[d], block_begin[d+1]) are the regular lines of direction d; the last
-    // blocks (one per diagonal direction) are the anomalous lines
-    const int b = blockIdx.x;
+    // Batch: consecutive blocks are the same line group of consecutive frames, so every frame's long
+    // horizontal lines are dispatched first.  Per frame, blocks [block_begin[d], block_begin[d+1]) are the
+    // regular lines of direction d; the last blocks (one per diagonal direction) are the anomalous lines.
+    const int frame = blockIdx.x % a.B;
+    const int b = blockIdx.x / a.B;
+    AggFrame fr;
+    fr.img = a.img + (size_t)frame * a.W * a.H;
+    fr.census_l = a.census_l + (size_t)frame * a.W * a.H;
+    fr.census_r = a.census_r + (size_t)frame * a.W * a.H;
+    fr.planes = a.planes + (size_t)frame * 8 * a.plane_bytes;
+    fr.extras = a.extras + (size_t)frame * 4 * a.H * a.Dp;
     if (b >= a.block_begin[8]) {
-        agg_anomalous<DPL, PAD>(a, lut_s, 4 + (b - a.block_begin[8]));
+        agg_anomalous<DPL, PAD, LPP>(a, fr, lut_s, 4 + (b - a.block_begin[8]));
         return;
     }
     int dir = 0;
     while (dir + 1 < a.ndirs && b >= a.block_begin[dir + 1]) ++dir;
     const int grp = b - a.block_begin[dir];
-    if (a.dy[dir] == 0)      agg_regular<DPL, PAD, AGG_H>(a, lut_s, dir, grp);
-    else if (a.dx[dir] == 0) agg_regular<DPL, PAD, AGG_V>(a, lut_s, dir, grp);
-    else                     agg_regular<DPL, PAD, AGG_D>(a, lut_s, dir, grp);
+    // the horizontal lines are the longest serial chains of the launch (W-1 dependent steps): their waves
+    // get issue priority over the shorter vertical/diagonal ones sharing the SIMD, also across frames in flight
+    if (a.dy[dir] == 0) __builtin_amdgcn_s_setprio(3);
+    if (a.dy[dir] == 0)      agg_regular<DPL, PAD, LPP, AGG_H>(a, fr, lut_s, dir, grp);
+    else if (a.dx[dir] == 0) agg_regular<DPL, PAD, LPP, AGG_V>(a, fr, lut_s, dir, grp);
+    else                     agg_regular<DPL, PAD, LPP, AGG_D>(a, fr, lut_s, dir, grp);
 }
 
 // ============================================================================================
@@ -564,6 +672,9 @@ __global__ __launch_bounds__(256) void sgm_sum_k(const uint8_t* __restrict__ pla
     const int x = t / (Dp >> 3);
     const int chunk = t - x * (Dp >> 3);
     const size_t off = ((size_t)row * W + x) * Dp + chunk * 8;
+    planes += (size_t)blockIdx.z * 8 * plane_bytes;                     // batch: z = frame
+    extras += (size_t)blockIdx.z * 4 * H * Dp;
+    S += (size_t)blockIdx.z * W * H * Dp;
 
     unsigned acc[8];
     if (accumulate) {                                    // Q14: S was not reset since the last frame
@@ -658,7 +769,10 @@ __global__ __launch_bounds__(WTA_T) void sgm_wta_k(const uint16_t* __restrict__ 
     const int x0 = blockIdx.x * WTA_T;
     const int i = threadIdx.x;
     const int x = x0 + i;
-    const uint16_t* Srow = S + (size_t)row * W * Dp;
+    const size_t frame_px = (size_t)blockIdx.z * W * H;                // batch: z = frame
+    const uint16_t* Srow = S + (frame_px + (size_t)row * W) * Dp;
+    disp_l += frame_px;
+    disp_r += frame_px;
 
     WtaState sl, sr;
     sl.m1 = sl.m2 = 0xFFFFu; sl.d1 = -1; sl.c1 = sl.c2 = 0xFFFFu; sl.pv = 0xFFFFu; sl.want_next = false;
@@ -710,6 +824,8 @@ __global__ __launch_bounds__(256) void sgm_lrcheck_k(float* __restrict__ dl, con
     const int y = blockIdx.y;
     if (x >= W) return;
     const float inf = __builtin_inff();
+    dl += (size_t)blockIdx.z * W * H;                                   // batch: z = frame
+    dr += (size_t)blockIdx.z * W * H;
     const size_t idx = (size_t)y * W + x;
     const float d = dl[idx];
     if (d == inf) return;
@@ -776,6 +892,10 @@ __global__ __launch_bounds__(256) void sgm_speckle_tile_k(const float* __restric
     __shared__ int cnt[SPK_N];
     const int tx0 = blockIdx.x * SPK_TW, ty0 = blockIdx.y * SPK_TH;
     const float inf = __builtin_inff();
+    {
+        const size_t frame_px = (size_t)blockIdx.z * W * H;            // batch: z = frame (labels are per-frame pixel indices)
+        disp += frame_px; label += frame_px; local_size += frame_px; total += frame_px;
+    }
     for (int i = threadIdx.x; i < SPK_N; i += 256) {
         const int x = tx0 + (i & (SPK_TW - 1)), y = ty0 + (i / SPK_TW);
         const float v = (x < W && y < H) ? disp[(size_t)y * W + x] : inf;
@@ -827,6 +947,8 @@ __global__ __launch_bounds__(256) void sgm_speckle_border_k(const float* __restr
     if (x >= W) return;
     const int lx = x & (SPK_TW - 1), ly = y & (SPK_TH - 1);
     if (ly != 0 && lx != 0 && lx != SPK_TW - 1) return;
+    disp += (size_t)blockIdx.z * W * H;                                 // batch: z = frame
+    label += (size_t)blockIdx.z * W * H;
     const int p = y * W + x;
     const float v = disp[p];
     if (v == __builtin_inff()) return;
@@ -847,6 +969,9 @@ __global__ __launch_bounds__(256) void sgm_speckle_total_k(const int* __restrict
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
+    label += (size_t)blockIdx.y * n;                                    // batch: y = frame
+    local_size += (size_t)blockIdx.y * n;
+    total += (size_t)blockIdx.y * n;
     const int c = local_size[p];
     if (c == 0) return;
     int r = p;
@@ -860,6 +985,9 @@ __global__ __launch_bounds__(256) void sgm_speckle_apply_k(float* __restrict__ d
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
+    disp += (size_t)blockIdx.y * n;                                     // batch: y = frame
+    label += (size_t)blockIdx.y * n;
+    total += (size_t)blockIdx.y * n;
     int r = label[p];
     if (r < 0) return;
     for (int q = label[r]; q != r; q = label[r]) r = q;
@@ -905,6 +1033,8 @@ __global__ __launch_bounds__(64) void sgm_median_prep_k(const float* __restrict_
 {
     const int l = threadIdx.x, tq = blockIdx.x, g = blockIdx.y;
     const int y = 1 + 64 * g + l;
+    disp += (size_t)blockIdx.z * W * H;                                 // batch: z = frame
+    P += (size_t)blockIdx.z * gridDim.y * Tq * MED_NE * 64;
     float e[MED_NE][4];
 #pragma unroll
     for (int k = 0; k < MED_NE; ++k)
@@ -943,6 +1073,8 @@ __global__ __launch_bounds__(64 * MED_WAVES) void sgm_median_serial_k(float* __r
     const int rows = H - 2;
     if (rows <= 0 || W <= 2) return;
     const int groups = (rows + 63) / 64;
+    disp += (size_t)blockIdx.x * W * H;                              // batch: one workgroup per frame
+    P += (size_t)blockIdx.x * groups * Tq * MED_NE * 64;
     const int t_end = 4 * Tq;                                        // >= W + MED_LAG: lane 63 reaches column W-1 at t = W-1+MED_LAG
 
     for (int gbase = 0; gbase < groups; gbase += MED_WAVES) {
@@ -1054,11 +1186,17 @@ __global__ __launch_bounds__(64 * MED_WAVES) void sgm_median_serial_k(float* __r
 // host-callable launchers
 // ============================================================================================
 
-template <int DPL>
+extern "C" size_t sgmd_census_slack(const sgmd_geom* g)
+{
+    // lowest census-right index read is p - (dmin + Dp - 1) with p >= 0; round up to 256 B
+    return (((size_t)g->dmin + g->Dp + 8) * sizeof(uint32_t) + 255) & ~(size_t)255;
+}
+
+template <int DPL, int LPP>
 static void launch_aggregate(const AggArgs& a, int blocks, bool pad, hipStream_t st)
 {
-    if (pad) hipLaunchKernelGGL((sgm_aggregate_k<DPL, true>), dim3(blocks), dim3(64), 0, st, a);
-    else     hipLaunchKernelGGL((sgm_aggregate_k<DPL, false>), dim3(blocks), dim3(64), 0, st, a);
+    if (pad) hipLaunchKernelGGL((sgm_aggregate_k<DPL, true, LPP>), dim3(blocks), dim3(64), 0, st, a);
+    else     hipLaunchKernelGGL((sgm_aggregate_k<DPL, false, LPP>), dim3(blocks), dim3(64), 0, st, a);
 }
 
 extern "C" {
@@ -1189,7 +1327,7 @@ int sgmd_timer_elapsed(int ord, void* timer, int from, int to, float* ms)
 int sgmd_census(int ord, void* stream, const sgmd_geom* g, const void* left, const void* right, void* cl, void* cr)
 {
     HIP_TRY(hipSetDevice(ord));
-    dim3 grid((g->W + 63) / 64, (g->H + 3) / 4, 2);
+    dim3 grid((g->W + 63) / 64, (g->H + 3) / 4, 2 * g->B);
     hipLaunchKernelGGL(sgm_census_k, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)left,
                        (const uint8_t*)right, (uint32_t*)cl, (uint32_t*)cr, g->W, g->H);
     HIP_TRY(hipGetLastError());
@@ -1200,7 +1338,7 @@ int sgmd_cost(int ord, void* stream, const sgmd_geom* g, const void* cl, const v
 {
     HIP_TRY(hipSetDevice(ord));
     const long long total = (long long)g->W * g->H * (g->Dp / 16);
-    dim3 grid((unsigned)((total + 255) / 256));
+    dim3 grid((unsigned)((total + 255) / 256), g->B);
     hipLaunchKernelGGL(sgm_cost_k, grid, dim3(256), 0, (hipStream_t)stream, (const uint32_t*)cl, (const uint32_t*)cr,
                        (uint8_t*)cost, g->W, g->H, g->D, g->Dp, g->dmin);
     HIP_TRY(hipGetLastError());
@@ -1208,17 +1346,21 @@ int sgmd_cost(int ord, void* stream, const sgmd_geom* g, const void* cl, const v
 }
 
 int sgmd_aggregate(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* paths, const void* img_left,
-                   const void* cost, const void* lut, void* planes, size_t plane_bytes, void* extras)
+                   const void* census_l, const void* census_r, const void* lut, void* planes, size_t plane_bytes,
+                   void* extras)
 {
     HIP_TRY(hipSetDevice(ord));
     AggArgs a;
     a.img = (const uint8_t*)img_left;
-    a.cost = (const uint8_t*)cost;
+    a.census_l = (const uint32_t*)census_l;
+    a.census_r = (const uint32_t*)census_r;
+    a.dmin = g->dmin;
     a.lut = (const uint16_t*)lut;
     a.planes = (uint8_t*)planes;
     a.plane_bytes = plane_bytes;
     a.extras = (uint8_t*)extras;
     a.W = g->W; a.H = g->H; a.D = g->D; a.Dp = g->Dp;
+    a.B = g->B;
     a.p1 = paths->p1;
     a.ndirs = paths->ndirs;
     a.ghost_zero = paths->ghost_zero;
@@ -1228,22 +1370,31 @@ int sgmd_aggregate(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* 
         a.block_begin[d] = blocks;
         if (d < paths->ndirs) {
             const int nlines = (paths->dy[d] == 0) ? g->H : g->W;
-            blocks += (nlines + 3) / 4;
+            const int lines_per_wave = 64 / g->LPP;
+            blocks += (nlines + lines_per_wave - 1) / lines_per_wave;
         }
     }
     a.block_begin[8] = blocks;
     if (paths->ndirs > 4) blocks += 4;                 // one extra wave per diagonal direction: its anomalous line
+    blocks *= g->B;                                    // every frame of the batch in the same launch
     const bool pad = (g->D != g->Dp);
     hipStream_t st = (hipStream_t)stream;
-    switch (g->DPL) {
-    case 2:  launch_aggregate<2>(a, blocks, pad, st); break;
-    case 4:  launch_aggregate<4>(a, blocks, pad, st); break;
-    case 8:  launch_aggregate<8>(a, blocks, pad, st); break;
-    case 12: launch_aggregate<12>(a, blocks, pad, st); break;
-    case 16: launch_aggregate<16>(a, blocks, pad, st); break;
-    case 32: launch_aggregate<32>(a, blocks, pad, st); break;
+    // (DPL, LPP): disparities per lane x lanes per pixel = Dp.  16 lanes per pixel (4 lines per wave) gives
+    // the shortest serial step; 8 lanes per pixel (8 lines per wave) spends ~40 % fewer VALU instructions
+    // per cell and is what a batch of frames (VALU-bound) uses.
+    const int key = g->LPP * 100 + g->DPL;
+    switch (key) {
+    case 1602: launch_aggregate<2, 16>(a, blocks, pad, st); break;
+    case 1604: launch_aggregate<4, 16>(a, blocks, pad, st); break;
+    case 1608: launch_aggregate<8, 16>(a, blocks, pad, st); break;
+    case 1612: launch_aggregate<12, 16>(a, blocks, pad, st); break;
+    case 1616: launch_aggregate<16, 16>(a, blocks, pad, st); break;
+    case 1632: launch_aggregate<32, 16>(a, blocks, pad, st); break;
+    case 804:  launch_aggregate<4, 8>(a, blocks, pad, st); break;
+    case 808:  launch_aggregate<8, 8>(a, blocks, pad, st); break;
+    case 816:  launch_aggregate<16, 8>(a, blocks, pad, st); break;
     default:
-        fprintf(stderr, "sgm_mi355x: unsupported DPL %d\n", g->DPL);
+        fprintf(stderr, "sgm_mi355x: unsupported lanes-per-pixel/DPL combination %d/%d\n", g->LPP, g->DPL);
         return -1;
     }
     HIP_TRY(hipGetLastError());
@@ -1256,7 +1407,7 @@ int sgmd_sum(int ord, void* stream, const sgmd_geom* g, int ndirs, const void* p
 {
     HIP_TRY(hipSetDevice(ord));
     const int per_row = g->W * (g->Dp / 8);
-    dim3 grid((per_row + 255) / 256, g->H);
+    dim3 grid((per_row + 255) / 256, g->H, g->B);
     hipLaunchKernelGGL(sgm_sum_k, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)planes, plane_bytes, ndirs,
                        (const uint8_t*)extras, (const sgmd_row_extra*)row_extras, (const int*)row_extra_count, row_cap,
                        accumulate, (uint16_t*)S, g->W, g->H, g->Dp);
@@ -1268,7 +1419,7 @@ int sgmd_wta(int ord, void* stream, const sgmd_geom* g, const void* S, int check
              int want_right, void* disp_l, void* disp_r)
 {
     HIP_TRY(hipSetDevice(ord));
-    dim3 grid((g->W + WTA_T - 1) / WTA_T, g->H);
+    dim3 grid((g->W + WTA_T - 1) / WTA_T, g->H, g->B);
     hipLaunchKernelGGL(sgm_wta_k, grid, dim3(WTA_T), 0, (hipStream_t)stream, (const uint16_t*)S, (float*)disp_l,
                        (float*)disp_r, g->W, g->H, g->D, g->Dp, g->dmin, check_unique, one_minus_ratio, want_right);
     HIP_TRY(hipGetLastError());
@@ -1278,7 +1429,7 @@ int sgmd_wta(int ord, void* stream, const sgmd_geom* g, const void* S, int check
 int sgmd_lrcheck(int ord, void* stream, const sgmd_geom* g, void* disp_l, const void* disp_r, float thres)
 {
     HIP_TRY(hipSetDevice(ord));
-    dim3 grid((g->W + 255) / 256, g->H);
+    dim3 grid((g->W + 255) / 256, g->H, g->B);
     hipLaunchKernelGGL(sgm_lrcheck_k, grid, dim3(256), 0, (hipStream_t)stream, (float*)disp_l, (const float*)disp_r,
                        g->W, g->H, thres);
     HIP_TRY(hipGetLastError());
@@ -1291,10 +1442,10 @@ int sgmd_speckle(int ord, void* stream, const sgmd_geom* g, void* disp, float di
     HIP_TRY(hipSetDevice(ord));
     hipStream_t st = (hipStream_t)stream;
     const int n = g->W * g->H;
-    const dim3 lin((n + 255) / 256), b(256);
-    hipLaunchKernelGGL(sgm_speckle_tile_k, dim3((g->W + SPK_TW - 1) / SPK_TW, (g->H + SPK_TH - 1) / SPK_TH), b, 0, st,
+    const dim3 lin((n + 255) / 256, g->B), b(256);
+    hipLaunchKernelGGL(sgm_speckle_tile_k, dim3((g->W + SPK_TW - 1) / SPK_TW, (g->H + SPK_TH - 1) / SPK_TH, g->B), b, 0, st,
                        (const float*)disp, (int*)labels, (int*)sizes, (int*)totals, g->W, g->H, diff);
-    hipLaunchKernelGGL(sgm_speckle_border_k, dim3((g->W + 255) / 256, g->H), b, 0, st, (const float*)disp, (int*)labels,
+    hipLaunchKernelGGL(sgm_speckle_border_k, dim3((g->W + 255) / 256, g->H, g->B), b, 0, st, (const float*)disp, (int*)labels,
                        g->W, g->H, diff);
     hipLaunchKernelGGL(sgm_speckle_total_k, lin, b, 0, st, (const int*)labels, (const int*)sizes, (int*)totals, n);
     hipLaunchKernelGGL(sgm_speckle_apply_k, lin, b, 0, st, (float*)disp, (const int*)labels, (const int*)totals, n,
@@ -1307,7 +1458,7 @@ size_t sgmd_median_scratch_bytes(const sgmd_geom* g)
 {
     const int groups = (g->H - 2 + 63) / 64;
     if (groups <= 0) return 16;
-    return (size_t)groups * med_tq(g->W) * MED_NE * 64 * sizeof(float4);
+    return (size_t)g->B * groups * med_tq(g->W) * MED_NE * 64 * sizeof(float4);
 }
 
 int sgmd_median(int ord, void* stream, const sgmd_geom* g, void* disp, void* scratch)
@@ -1318,10 +1469,10 @@ int sgmd_median(int ord, void* stream, const sgmd_geom* g, void* disp, void* scr
     const int groups = (rows + 63) / 64;
     const int Tq = med_tq(g->W);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(sgm_median_prep_k, dim3(Tq, groups), dim3(64), 0, st, (const float*)disp, (float4*)scratch, g->W,
+    hipLaunchKernelGGL(sgm_median_prep_k, dim3(Tq, groups, g->B), dim3(64), 0, st, (const float*)disp, (float4*)scratch, g->W,
                        g->H, Tq);
     const int waves = groups < MED_WAVES ? groups : MED_WAVES;
-    hipLaunchKernelGGL(sgm_median_serial_k, dim3(1), dim3(64 * waves), 0, st, (float*)disp, (float4*)scratch, g->W,
+    hipLaunchKernelGGL(sgm_median_serial_k, dim3(g->B), dim3(64 * waves), 0, st, (float*)disp, (float4*)scratch, g->W,
                        g->H, Tq);
     HIP_TRY(hipGetLastError());
     return 0;

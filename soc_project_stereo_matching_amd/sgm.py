@@ -94,6 +94,9 @@ def load_library() -> C.CDLL:
     L.sgm_destroy.argtypes = [C.c_void_p]
     L.sgm_set_honor_num_paths.argtypes = [C.c_void_p, C.c_int]
     L.sgm_keep_stages.argtypes = [C.c_void_p, C.c_int]
+    L.sgm_set_batch.argtypes = [C.c_void_p, C.c_int]
+    L.sgm_set_batch.restype = C.c_bool
+    L.sgm_select_frame.argtypes = [C.c_void_p, C.c_int]
     for f in (L.sgm_initialize, L.sgm_reset):
         f.argtypes = [C.c_void_p, C.c_uint16, C.c_uint16, opt_p]
         f.restype = C.c_bool
@@ -226,13 +229,27 @@ class SGM(_StageReader):
 class SGMInstance(_StageReader):
     """Explicit instance (extension): own HIP stream and buffers on one GPU."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, batch=1):
         self.lib = load_library()
         self.handle = self.lib.sgm_create(device)
         if not self.handle:
             raise RuntimeError(f"sgm_create({device}) failed: no usable gfx950 device (no CPU fallback)")
         self.device = device
         self.shape = None
+        self.batch = 1
+        if batch != 1:
+            self.set_batch(batch)
+
+    def set_batch(self, frames: int) -> bool:
+        """Frames per match call ([frames][H][W] arrays); takes effect at the next initialize/reset."""
+        ok = bool(self.lib.sgm_set_batch(self.handle, frames))
+        if ok:
+            self.batch = frames
+        return ok
+
+    def select_frame(self, frame: int):
+        """Which frame of the batch read_stage() returns."""
+        self.lib.sgm_select_frame(self.handle, frame)
 
     def close(self):
         if self.handle:
@@ -273,7 +290,11 @@ class SGMInstance(_StageReader):
         return ok
 
     def match(self, left, right):
+        """left/right: uint8 [H][W], or [batch][H][W] when the instance has a batch > 1."""
         left, right = _u8(left), _u8(right)
+        want = self.shape[:2] if self.batch == 1 else (self.batch,) + tuple(self.shape[:2])
+        if self.shape is not None and tuple(left.shape) != tuple(want):
+            raise ValueError(f"expected images of shape {want}, got {left.shape}")
         out = np.empty(left.shape, np.float32)
         ok = self.lib.sgm_match(self.handle, left.ctypes.data, right.ctypes.data, out.ctypes.data)
         return out if ok else None

@@ -183,3 +183,28 @@ def test_full_size_properties_kitti_batch(oracle):
             assert (S_total >= planes).all()
     assert len(set(digests)) == 8
     a.close(); b.close()
+
+
+def test_batched_frames_one_launch_per_stage(oracle):
+    """sgm_set_batch: every kernel processes all frames of a batch in one launch; each frame must still equal
+    the oracle on every stage (different content per frame; incl. a W < H shape that clears the planes)."""
+    import soc_project_stereo_matching_amd as S
+    from oracle.pyoracle import default_option
+    for (w, h, d, B) in [(200, 64, 64, 3), (30, 70, 8, 4), (1242, 375, 128, 2)]:
+        opt = default_option(d, min_speckle_area=12)
+        inst = S.SGMInstance(0, batch=B)
+        inst.keep_stages(True)
+        frames = [oracle.synth_pair(w, h, d, 0xBA7C00 + 31 * k + w) for k in range(B)]
+        left = np.stack([f[0] for f in frames])
+        right = np.stack([f[1] for f in frames])
+        assert inst.reset(w, h, opt)
+        out = inst.match(left, right)
+        assert out is not None and out.shape == (B, h, w)
+        for k in range(B):
+            want = oracle.run(frames[k][0], frames[k][1], opt)
+            inst.select_frame(k)
+            got = inst.read_stages()
+            for n in STAGE_NAMES:
+                assert_same(got[n], want[n], f"batch {w}x{h} frame {k}: {n}")
+            assert_same(out[k], want["final"], f"batch {w}x{h} frame {k}: result")
+        inst.close()
