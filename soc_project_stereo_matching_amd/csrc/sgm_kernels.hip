@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(256) void sgm_speckle_apply_k(float* __restrict__ d
 #define MED_SKEW 3
 #define MED_LAG (MED_SKEW * 63)
 #define MED_RING 128
-#define MED_WAVES 16
+#define MED_WAVES 8                // waves (64 rows each) per workgroup: 512 threads leave 256 VGPRs per lane
 
 static __device__ __forceinline__ void cswapf(float& a, float& b)
 {
@@ -1051,7 +1051,12 @@ __global__ __launch_bounds__(64) void sgm_median_prep_k(const float* __restrict_
             // it (row 0 of the image is never modified; later bands overwrite it, see the serial kernel).
             if (x + 1 >= 0 && x + 1 <= W - 1) e[5][j] = rm[x + 1];
             if (x < 0 || x > W - 1) continue;
-            if (x == 0 || x == W - 1) { e[0][j] = r0[x]; continue; }          // border column: passed through
+            if (x == 0 || x == W - 1) {
+                // border column: all five equal -> s3 = s4 = the original, the serial kernel passes it through
+                const float v = r0[x];
+                e[0][j] = e[1][j] = e[2][j] = e[3][j] = e[4][j] = v;
+                continue;
+            }
             float v0 = r0[x], v1 = r0[x + 1], v2 = r1[x - 1], v3 = r1[x], v4 = r1[x + 1];
             cswapf(v0, v1); cswapf(v3, v4); cswapf(v2, v4); cswapf(v2, v3); cswapf(v1, v4);
             cswapf(v0, v3); cswapf(v0, v2); cswapf(v1, v3); cswapf(v1, v2);
@@ -1063,18 +1068,20 @@ __global__ __launch_bounds__(64) void sgm_median_prep_k(const float* __restrict_
         P[(((size_t)g * Tq + tq) * MED_NE + k) * 64 + l] = make_float4(e[k][0], e[k][1], e[k][2], e[k][3]);
 }
 
-__global__ __launch_bounds__(64 * MED_WAVES) void sgm_median_serial_k(float* __restrict__ disp, float4* __restrict__ P,
-                                                                      int W, int H, int Tq)
+__global__ __launch_bounds__(64 * MED_WAVES) void sgm_median_serial_k(const float* __restrict__ disp, float4* __restrict__ P,
+                                                                      float4* __restrict__ O, int W, int H, int Tq)
 {
     __shared__ __attribute__((aligned(16))) float ring[MED_WAVES][MED_RING];
     __shared__ int prog[MED_WAVES];      // last column the wave's lane 63 has put into its ring
     __shared__ int cons[MED_WAVES];      // last column the wave has taken from the ring of the wave above
+    __shared__ float ring_dummy[64];
     const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
     const int rows = H - 2;
     if (rows <= 0 || W <= 2) return;
     const int groups = (rows + 63) / 64;
     disp += (size_t)blockIdx.x * W * H;                              // batch: one workgroup per frame
     P += (size_t)blockIdx.x * groups * Tq * MED_NE * 64;
+    O += (size_t)blockIdx.x * groups * Tq * 64;
     const int t_end = 4 * Tq;                                        // >= W + MED_LAG: lane 63 reaches column W-1 at t = W-1+MED_LAG
 
     for (int gbase = 0; gbase < groups; gbase += MED_WAVES) {
@@ -1082,12 +1089,17 @@ __global__ __launch_bounds__(64 * MED_WAVES) void sgm_median_serial_k(float* __r
         if (gbase > 0) {
             // the row above this band is the previous band's finished last row: put it where lane 0 of the
             // band's first wave expects the row above (plane 5), replacing the originals of the pre-pass
-            const float* const above = disp + (size_t)(64 * gbase) * W;
+            // (results live in the time-skewed buffer O until the un-skew kernel: row 64*gbase is lane 63 of
+            // group gbase-1, column c sits at time slot c + MED_LAG)
+            const float* const above = reinterpret_cast<const float*>(O + (size_t)(gbase - 1) * Tq * 64);
             for (int tq = threadIdx.x; tq < Tq; tq += blockDim.x) {
                 float v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    v[j] = __hip_atomic_load(above + min(4 * tq + j + 1, W - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int j = 0; j < 4; ++j) {
+                    const int t = min(4 * tq + j + 1, W - 1) + MED_LAG;
+                    v[j] = __hip_atomic_load(above + ((size_t)(t >> 2) * 64 + 63) * 4 + (t & 3), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+                }
                 P[(((size_t)gbase * Tq + tq) * MED_NE + 5) * 64] = make_float4(v[0], v[1], v[2], v[3]);
             }
             __threadfence();
@@ -1100,13 +1112,15 @@ __global__ __launch_bounds__(64 * MED_WAVES) void sgm_median_serial_k(float* __r
             const bool feeds_next = (wv + 1 < MED_WAVES) && (g + 1 < groups);
             const bool top_from_ring = wv > 0;
             const int yr = valid ? y : H - 2;
-            float* const out_row = disp + (size_t)yr * W;
+            float4* const Og = O + (size_t)g * Tq * 64 + l;
             const float* const top_row = disp + (size_t)(yr - 1) * W;
             const float4* Pg = P + (size_t)g * Tq * MED_NE * 64 + l;
 
             float o1 = 0.f, o2 = 0.f;                                // own outputs of the last two steps
             float T0 = 0.f;                                          // out(y-1, x-1)
             float T1 = top_row[0];                                   // out(y-1, x): column 0 is border, never modified
+            asm volatile("" : "+v"(T1));                             // retire this load here, not at its first use inside the loop
+            __builtin_amdgcn_sched_barrier(0);
             // pre-sorted neighbourhoods are read-only input: keep MED_PF batches (4 steps each) in flight
             float4 evr[MED_PF][MED_NE];
             auto load_batch = [&](float4 (&dst)[MED_NE], int t0) {
@@ -1114,32 +1128,22 @@ __global__ __launch_bounds__(64 * MED_WAVES) void sgm_median_serial_k(float* __r
 #pragma unroll
                 for (int k = 0; k < MED_NE; ++k) dst[k] = Pg[((size_t)tq * MED_NE + k) * 64];
             };
+            // issue the prologue groups strictly in order: the loop's s_waitcnt counts are the minimum over the
+            // prologue path and the back edge, and vmcnt retires in issue order
 #pragma unroll
-            for (int u = 0; u < MED_PF; ++u) load_batch(evr[u], 4 * u);
+            for (int u = 0; u < MED_PF; ++u) {
+                load_batch(evr[u], 4 * u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 
-            auto run_batch = [&](const float4 (&ev)[MED_NE], int t0) {
-                // ---- flow control between waves (LDS only) ----
-                if (top_from_ring) {
-                    const int need = min(t0 + 4, W - 1);
-                    while (__hip_atomic_load(&prog[wv - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
-                        __builtin_amdgcn_s_sleep(1);
-                }
-                if (feeds_next) {
-                    const int last = t0 + 3 - MED_LAG;               // last column lane 63 writes in this batch
-                    while (__hip_atomic_load(&cons[wv + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < last - (MED_RING - 8))
-                        __builtin_amdgcn_s_sleep(1);
-                }
-                asm volatile("" ::: "memory");
-                float tv[4];                                         // lane 0: out(y-1, t0+1 .. t0+4)
-                if (top_from_ring) {
-                    const float4 r = *reinterpret_cast<const float4*>(&ring[wv - 1][t0 & (MED_RING - 1)]);
-                    tv[0] = r.x; tv[1] = r.y; tv[2] = r.z; tv[3] = r.w;
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (l == 0) __hip_atomic_store(&cons[wv], t0 + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                } else {
-                    // top of a band: the row above comes with the pre-pass data (plane 5 of lane 0)
-                    tv[0] = ev[5].x; tv[1] = ev[5].y; tv[2] = ev[5].z; tv[3] = ev[5].w;
-                }
+            // lane 63 feeds the next wave through the ring; every other lane writes to a dummy slot instead of
+            // branching (slots more than ~100 columns behind the consumer are free, so the out-of-range
+            // columns lane 63 writes before/after its row are harmless)
+            float* const ring_dst = (l == 63) ? &ring[wv][0] : &ring_dummy[l];
+            const unsigned ring_mask = (l == 63) ? (MED_RING - 1) : 0u;
+
+            auto run_batch = [&](const float4 (&ev)[MED_NE], int t0, const float (&tv)[4]) {
+                float res[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int x = t0 + j - MED_SKEW * l;
@@ -1152,34 +1156,76 @@ __global__ __launch_bounds__(64 * MED_WAVES) void sgm_median_serial_k(float* __r
                     const float mid = __builtin_amdgcn_fmed3f(T0, T1, b);
                     const float s3 = fmaxf(fmaxf(fminf(e3, lo), fminf(e2, mid)), fmaxf(fminf(e1, hi), e0));
                     const float s4 = fmaxf(fmaxf(fminf(e4, lo), fminf(e3, mid)), fmaxf(fminf(e2, hi), e1));
-                    const float m = __builtin_amdgcn_fmed3f(s3, o1, s4);
-                    const bool active = valid && x >= 0 && x <= W - 1;
-                    const bool interior = active && x >= 1 && x <= W - 2;
-                    const float outv = interior ? m : e0;           // border columns pass the original through
-                    if (interior) out_row[x] = outv;
-                    if (x >= 0) { T0 = T1; T1 = b; }
+                    const float outv = __builtin_amdgcn_fmed3f(s3, o1, s4);   // border columns: s3 == s4 == original
+                    res[j] = outv;
+                    T0 = T1; T1 = b;
                     o2 = o1; o1 = outv;
-                    if (feeds_next && l == 63 && x >= 1 && x <= W - 1) ring[wv][(x - 1) & (MED_RING - 1)] = outv;
+                    ring_dst[(unsigned)(x - 1) & ring_mask] = outv;
                 }
-                if (feeds_next) {
-                    const int done = min(t0 + 3 - MED_LAG, W - 1);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (l == 63 && done >= 1) __hip_atomic_store(&prog[wv], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+                // results go to the time-skewed, lane-interleaved buffer O (one coalesced 1 KiB store per batch;
+                // storing straight into the image would touch 64 different rows per instruction); the un-skew
+                // kernel moves them into the image afterwards
+                Og[(size_t)(t0 >> 2) * 64] = make_float4(res[0], res[1], res[2], res[3]);
             };
 
             for (int tb = 0; tb < t_end; tb += 4 * MED_PF) {
+                // ---- flow control between waves, once per MED_PF batches (LDS only) ----
+                if (top_from_ring) {
+                    const int need = min(tb + 4 * MED_PF, W - 1);
+                    while (__hip_atomic_load(&prog[wv - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
+                        __builtin_amdgcn_s_sleep(1);
+                }
+                if (feeds_next) {
+                    const int last = tb + 4 * MED_PF - 1 - MED_LAG;  // last column lane 63 writes in this group
+                    while (__hip_atomic_load(&cons[wv + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < last - (MED_RING - 4 * MED_PF - 8))
+                        __builtin_amdgcn_s_sleep(1);
+                }
+                asm volatile("" ::: "memory");
+                float tvr[MED_PF][4];                                // lane 0: out(y-1, tb+1 .. tb+16)
+                if (top_from_ring) {
+#pragma unroll
+                    for (int u = 0; u < MED_PF; ++u) {
+                        const float4 r = *reinterpret_cast<const float4*>(&ring[wv - 1][(tb + 4 * u) & (MED_RING - 1)]);
+                        tvr[u][0] = r.x; tvr[u][1] = r.y; tvr[u][2] = r.z; tvr[u][3] = r.w;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (l == 0) __hip_atomic_store(&cons[wv], tb + 4 * MED_PF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
 #pragma unroll
                 for (int u = 0; u < MED_PF; ++u) {
                     const int t0 = tb + 4 * u;
-                    run_batch(evr[u], t0);
+                    if (!top_from_ring) {
+                        // top of a band: the row above comes with the pre-pass data (plane 5 of lane 0)
+                        tvr[u][0] = evr[u][5].x; tvr[u][1] = evr[u][5].y; tvr[u][2] = evr[u][5].z; tvr[u][3] = evr[u][5].w;
+                    }
+                    run_batch(evr[u], t0, tvr[u]);
                     load_batch(evr[u], t0 + 4 * MED_PF);
+                }
+                if (feeds_next) {
+                    const int done = min(tb + 4 * MED_PF - 1 - MED_LAG, W - 1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (l == 63 && done >= 1) __hip_atomic_store(&prog[wv], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
             if (l == 0) __hip_atomic_store(&cons[wv], 0x7FFFFFF0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         __syncthreads();                                             // band finished and stored before the next one reads it
     }
+}
+
+// results of the serial kernel: O[group][t/4][lane][t%4] with t = x + MED_SKEW*lane  ->  disp[y][x], interior only
+__global__ __launch_bounds__(256) void sgm_median_unskew_k(const float* __restrict__ O, float* __restrict__ disp, int W, int H,
+                                                           int Tq)
+{
+    const int x = 1 + blockIdx.x * 256 + threadIdx.x;
+    const int y = 1 + blockIdx.y;
+    if (x > W - 2) return;
+    const int groups = (H - 2 + 63) / 64;
+    O += (size_t)blockIdx.z * groups * Tq * 64 * 4;                    // batch: z = frame
+    disp += (size_t)blockIdx.z * W * H;
+    const int g = (y - 1) >> 6, l = (y - 1) & 63;
+    const int t = x + MED_SKEW * l;
+    disp[(size_t)y * W + x] = O[(((size_t)g * Tq + (t >> 2)) * 64 + l) * 4 + (t & 3)];
 }
 
 // ============================================================================================
@@ -1458,7 +1504,7 @@ size_t sgmd_median_scratch_bytes(const sgmd_geom* g)
 {
     const int groups = (g->H - 2 + 63) / 64;
     if (groups <= 0) return 16;
-    return (size_t)g->B * groups * med_tq(g->W) * MED_NE * 64 * sizeof(float4);
+    return (size_t)g->B * groups * med_tq(g->W) * (MED_NE + 1) * 64 * sizeof(float4);   // inputs (MED_NE planes) + results
 }
 
 int sgmd_median(int ord, void* stream, const sgmd_geom* g, void* disp, void* scratch)
@@ -1472,8 +1518,11 @@ int sgmd_median(int ord, void* stream, const sgmd_geom* g, void* disp, void* scr
     hipLaunchKernelGGL(sgm_median_prep_k, dim3(Tq, groups, g->B), dim3(64), 0, st, (const float*)disp, (float4*)scratch, g->W,
                        g->H, Tq);
     const int waves = groups < MED_WAVES ? groups : MED_WAVES;
-    hipLaunchKernelGGL(sgm_median_serial_k, dim3(g->B), dim3(64 * waves), 0, st, (float*)disp, (float4*)scratch, g->W,
-                       g->H, Tq);
+    float4* const results = (float4*)scratch + (size_t)g->B * groups * Tq * MED_NE * 64;
+    hipLaunchKernelGGL(sgm_median_serial_k, dim3(g->B), dim3(64 * waves), 0, st, (const float*)disp, (float4*)scratch, results,
+                       g->W, g->H, Tq);
+    hipLaunchKernelGGL(sgm_median_unskew_k, dim3((g->W - 2 + 255) / 256, g->H - 2, g->B), dim3(256), 0, st,
+                       (const float*)results, (float*)disp, g->W, g->H, Tq);
     HIP_TRY(hipGetLastError());
     return 0;
 }
