@@ -81,14 +81,15 @@ int sgmd_aggregate(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* 
                    const void* census_l, const void* census_r, const void* lut, void* planes, size_t plane_bytes,
                    void* extras);
 
-/* S = (accumulate ? S : 0) + sum of planes + anomalous-line visits.  u16 [H][W][Dp] */
-int sgmd_sum(int ord, void* stream, const sgmd_geom* g, int ndirs, const void* planes, size_t plane_bytes,
-             const void* extras, const void* row_extras, const void* row_extra_count, int row_cap,
-             int accumulate, void* S);
+/* S = (accumulate ? S : 0) + sum of planes + anomalous-line visits (u16 [H][W][Dp]) and, fused, the LEFT-view
+ * winner-take-all with uniqueness and sub-pixel (SemiGlobalMatching.c:374-443, inverse == 0) -> disp_l */
+int sgmd_sum_wta(int ord, void* stream, const sgmd_geom* g, int ndirs, const void* planes, size_t plane_bytes,
+                 const void* extras, const void* row_extras, const void* row_extra_count, int row_cap, int accumulate,
+                 void* S, int check_unique, float one_minus_ratio, void* disp_l);
 
-/* left and right-view winner-take-all, uniqueness, sub-pixel.  SemiGlobalMatching.c:374-443 */
-int sgmd_wta(int ord, void* stream, const sgmd_geom* g, const void* S, int check_unique, float one_minus_ratio,
-             int want_right, void* disp_l, void* disp_r);
+/* right-view winner-take-all on S[y][x+d][d] (SemiGlobalMatching.c:395-408) -> disp_r; needed by the LR check only */
+int sgmd_wta_right(int ord, void* stream, const sgmd_geom* g, const void* S, int check_unique, float one_minus_ratio,
+                   void* disp_r);
 
 /* SemiGlobalMatching.c:445-470 */
 int sgmd_lrcheck(int ord, void* stream, const sgmd_geom* g, void* disp_l, const void* disp_r, float thres);

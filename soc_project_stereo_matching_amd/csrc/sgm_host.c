@@ -418,12 +418,13 @@ static bool run_pipeline(sgm_instance* s, const void* d_left, const void* d_righ
     rc |= sgmd_aggregate(dev, st, g, &s->paths, d_left, s->d_census_l, s->d_census_r, s->d_lut, s->d_planes, s->plane_bytes,
                          s->d_extras);                                                          /* .c:94 */
     mark(s, 3);
-    rc |= sgmd_sum(dev, st, g, s->paths.ndirs, s->d_planes, s->plane_bytes, s->d_extras, s->d_row_extras,
-                   s->d_row_count, s->row_cap, s->s_is_zero ? 0 : 1, s->d_S);
+    rc |= sgmd_sum_wta(dev, st, g, s->paths.ndirs, s->d_planes, s->plane_bytes, s->d_extras, s->d_row_extras,
+                       s->d_row_count, s->row_cap, s->s_is_zero ? 0 : 1, s->d_S, o->is_check_unique ? 1 : 0,
+                       1 - o->uniqueness_ratio, d_out);                                         /* .c:94 sum, .c:99 */
     s->s_is_zero = false;                                                                       /* Q14 */
     mark(s, 4);
-    rc |= sgmd_wta(dev, st, g, s->d_S, o->is_check_unique ? 1 : 0, 1 - o->uniqueness_ratio,
-                   o->is_check_lr ? 1 : 0, d_out, s->d_disp_r);                                 /* .c:99,105 */
+    if (o->is_check_lr)
+        rc |= sgmd_wta_right(dev, st, g, s->d_S, o->is_check_unique ? 1 : 0, 1 - o->uniqueness_ratio, s->d_disp_r);  /* .c:105 */
     if (s->keep_stages) rc |= sgmd_d2d_async(dev, st, s->d_snap_wta, d_out, px_bytes);
     mark(s, 5);
     if (o->is_check_lr) rc |= sgmd_lrcheck(dev, st, g, d_out, s->d_disp_r, o->lrcheck_thres);   /* .c:109 */

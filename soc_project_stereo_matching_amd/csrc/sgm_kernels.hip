@@ -207,6 +207,34 @@ static __device__ __forceinline__ void load_cells(const uint8_t* p, CellVec<DPL>
 
 // L_r planes are written once and read once by the sum kernel: stream them past the caches (nt) so the
 // cost volume, which all eight directions re-read, keeps its place in L2 / Infinity Cache.
+// read-once variant (non-temporal) of load_cells
+template <int DPL>
+static __device__ __forceinline__ void load_cells_nt(const uint8_t* p, CellVec<DPL>& v)
+{
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    if constexpr (DPL == 2) {
+        v.w[0] = __builtin_nontemporal_load(reinterpret_cast<const unsigned short*>(p));
+    } else if constexpr (DPL == 4) {
+        v.w[0] = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(p));
+    } else if constexpr (DPL == 8) {
+        const v2u t = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(p));
+        v.w[0] = t.x; v.w[1] = t.y;
+    } else if constexpr (DPL == 12) {
+        const v2u t = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(p));
+        v.w[0] = t.x; v.w[1] = t.y;
+        v.w[2] = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(p + 8));
+    } else if constexpr (DPL == 16) {
+        const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p));
+        v.w[0] = t.x; v.w[1] = t.y; v.w[2] = t.z; v.w[3] = t.w;
+    } else {
+        const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p));
+        const v4u u = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p + 16));
+        v.w[0] = t.x; v.w[1] = t.y; v.w[2] = t.z; v.w[3] = t.w;
+        v.w[4] = u.x; v.w[5] = u.y; v.w[6] = u.z; v.w[7] = u.w;
+    }
+}
+
 template <int DPL>
 static __device__ __forceinline__ void store_cells(uint8_t* p, const CellVec<DPL>& v)
 {
@@ -659,71 +687,6 @@ __global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
 // S = [S +] sum over directions of L_r (+ the second visits of the anomalous lines)
 // ============================================================================================
 
-__global__ __launch_bounds__(256) void sgm_sum_k(const uint8_t* __restrict__ planes, size_t plane_bytes, int ndirs,
-                                                 const uint8_t* __restrict__ extras,
-                                                 const sgmd_row_extra* __restrict__ row_extras,
-                                                 const int* __restrict__ row_extra_count, int row_cap,
-                                                 int accumulate, uint16_t* __restrict__ S, int W, int H, int Dp)
-{
-    const int per_row = W * (Dp >> 3);
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= per_row) return;
-    const int row = blockIdx.y;
-    const int x = t / (Dp >> 3);
-    const int chunk = t - x * (Dp >> 3);
-    const size_t off = ((size_t)row * W + x) * Dp + chunk * 8;
-    planes += (size_t)blockIdx.z * 8 * plane_bytes;                     // batch: z = frame
-    extras += (size_t)blockIdx.z * 4 * H * Dp;
-    S += (size_t)blockIdx.z * W * H * Dp;
-
-    unsigned acc[8];
-    if (accumulate) {                                    // Q14: S was not reset since the last frame
-        const uint4 s = *reinterpret_cast<const uint4*>(S + off);
-        acc[0] = s.x & 0xFFFF; acc[1] = s.x >> 16; acc[2] = s.y & 0xFFFF; acc[3] = s.y >> 16;
-        acc[4] = s.z & 0xFFFF; acc[5] = s.z >> 16; acc[6] = s.w & 0xFFFF; acc[7] = s.w >> 16;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = 0;
-    }
-    auto add8 = [&](const uint8_t* p) {
-        typedef unsigned v2u __attribute__((ext_vector_type(2)));
-        const v2u vv = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(p));    // read once
-        const uint2 v = make_uint2(vv.x, vv.y);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc[i] += (v.x >> (8 * i)) & 0xFF;
-            acc[4 + i] += (v.y >> (8 * i)) & 0xFF;
-        }
-    };
-    for (int d = 0; d < ndirs; ++d) add8(planes + (size_t)d * plane_bytes + off);
-    if (ndirs > 4) {
-        const int n = row_extra_count[row];
-        for (int j = 0; j < n; ++j) {
-            const sgmd_row_extra e = row_extras[row * row_cap + j];
-            if ((e.col_slot & 0xFFFF) == x)
-                add8(extras + ((size_t)(e.col_slot >> 16) * H + e.step) * Dp + chunk * 8);
-        }
-    }
-    uint4 o;
-    o.x = (acc[0] & 0xFFFF) | (acc[1] << 16);
-    o.y = (acc[2] & 0xFFFF) | (acc[3] << 16);
-    o.z = (acc[4] & 0xFFFF) | (acc[5] << 16);
-    o.w = (acc[6] & 0xFFFF) | (acc[7] << 16);
-    *reinterpret_cast<uint4*>(S + off) = o;
-}
-
-// ============================================================================================
-// winner-take-all, left and right view  (ref :374-443)
-//
-// One lane = one pixel; a workgroup handles WTA_T consecutive pixels of a row and walks the
-// disparity range in chunks of WTA_DC, staging S through LDS so both the left view (S[x][d])
-// and the right view (S[x+d][d], ref :397-408) read conflict-free LDS instead of strided HBM.
-// ============================================================================================
-
-#define WTA_T 128
-#define WTA_DC 64
-#define WTA_LD (WTA_DC + 2)       // u16 row stride (33 dwords: odd, conflict-free lane stride)
-
 struct WtaState {
     unsigned m1, m2;   // smallest cost (lowest d wins ties, ref :390) and smallest among the others (ref :413-419)
     int d1;            // index (d - dmin) of m1, -1 if nothing beat 65535
@@ -759,11 +722,123 @@ static __device__ __forceinline__ float wta_finish(const WtaState& s, int D, int
     return (float)(s.d1 + dmin) + (float)(c1 - c2) / ((float)denom * 2.0f);     // ref :440
 }
 
-__global__ __launch_bounds__(WTA_T) void sgm_wta_k(const uint16_t* __restrict__ S, float* __restrict__ disp_l,
-                                                   float* __restrict__ disp_r, int W, int H, int D, int Dp, int dmin,
-                                                   int check_unique, float one_minus_ratio, int want_right)
+// OR over the 16 lanes of a DPP row, result in every lane
+static __device__ __forceinline__ unsigned row_allor(unsigned v)
 {
-    __shared__ unsigned short tl[WTA_T * WTA_LD];
+    v |= dpp_perm<DPP_QUAD_XOR1>(v);
+    v |= dpp_perm<DPP_QUAD_XOR2>(v);
+    v |= dpp_perm<DPP_ROW_HALF_MIRROR>(v);
+    v |= dpp_perm<DPP_ROW_MIRROR>(v);
+    return v;
+}
+
+// S = [S +] sum of the L_r planes (+ second visits of the anomalous lines), and -- while the 16 lanes of a
+// pixel still hold its S vector in registers -- the LEFT-view winner-take-all (ref :374-443 with
+// inverse == 0).  16 lanes per pixel, DPL disparities per lane; the kernel is HBM-bound (it streams the 8
+// planes once), so the WTA arithmetic rides along for free.
+//   key = S << 16 | d: the row-wide minimum key is the first minimum the reference's strict '>' finds.
+template <int DPL>
+__global__ __launch_bounds__(256) void sgm_sum_wta_k(const uint8_t* __restrict__ planes, size_t plane_bytes, int ndirs,
+                                                     const uint8_t* __restrict__ extras,
+                                                     const sgmd_row_extra* __restrict__ row_extras,
+                                                     const int* __restrict__ row_extra_count, int row_cap, int accumulate,
+                                                     uint16_t* __restrict__ S, float* __restrict__ disp_l, int W, int H, int D,
+                                                     int Dp, int dmin, int check_unique, float one_minus_ratio)
+{
+    const int sub = threadIdx.x & 15;
+    const int xr = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool inside = xr < W;
+    const int x = inside ? xr : W - 1;                                  // keep the DPP rows converged; stores are masked
+    const int row = blockIdx.y;
+    const size_t off = ((size_t)row * W + x) * Dp + sub * DPL;
+    planes += (size_t)blockIdx.z * 8 * plane_bytes;                     // batch: z = frame
+    extras += (size_t)blockIdx.z * 4 * H * Dp;
+    S += (size_t)blockIdx.z * W * H * Dp;
+    disp_l += (size_t)blockIdx.z * W * H;
+
+    unsigned acc[DPL];
+    if (accumulate) {                                    // Q14: S was not reset since the last frame
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) acc[i] = S[off + i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) acc[i] = 0;
+    }
+    auto add_cells = [&](const uint8_t* p, bool nt) {
+        CellVec<DPL> v;
+        if (nt) load_cells_nt<DPL>(p, v); else load_cells<DPL>(p, v);
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) acc[i] += (v.w[i >> 2] >> (8 * (i & 3))) & 0xFF;
+    };
+    for (int d = 0; d < ndirs; ++d) add_cells(planes + (size_t)d * plane_bytes + off, true);
+    if (ndirs > 4) {
+        const int n = row_extra_count[row];
+        for (int j = 0; j < n; ++j) {
+            const sgmd_row_extra e = row_extras[row * row_cap + j];
+            if ((e.col_slot & 0xFFFF) == x)
+                add_cells(extras + ((size_t)(e.col_slot >> 16) * H + e.step) * Dp + sub * DPL, false);
+        }
+    }
+    if (inside) {
+        unsigned short* dst = S + off;
+#pragma unroll
+        for (int i = 0; i < DPL; i += 2)
+            *reinterpret_cast<unsigned*>(dst + i) = (acc[i] & 0xFFFFu) | (acc[i + 1] << 16);
+    }
+
+    // ---- left-view WTA over the 16 lanes of the pixel ----
+    unsigned key[DPL];
+    unsigned kmin = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+        const int idx = sub * DPL + i;
+        key[i] = (idx < D) ? (((acc[i] & 0xFFFFu) << 16) | (unsigned)idx) : 0xFFFFFFFFu;
+        kmin = min(kmin, key[i]);
+    }
+    const unsigned kbest = row_allmin<16>(kmin);
+    unsigned k2 = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) k2 = min(k2, key[i] == kbest ? 0xFFFFFFFFu : key[i]);
+    const unsigned ksecond = row_allmin<16>(k2);
+    const int dbest = (int)(kbest & 0xFFFFu);
+    unsigned nb = 0;                                     // S[best-1] | S[best+1] << 16 (ref :432-435)
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+        const int idx = sub * DPL + i;
+        if (idx == dbest - 1) nb |= acc[i] & 0xFFFFu;
+        if (idx == dbest + 1) nb |= acc[i] << 16;
+    }
+    nb = row_allor(nb);
+    if (inside && sub == 0) {
+        WtaState st;
+        st.m1 = kbest >> 16;
+        st.m2 = ksecond >> 16;                           // 0xFFFF if there is no other disparity, as ref :381
+        st.d1 = (kbest == 0xFFFFFFFFu) ? -1 : dbest;
+        st.c1 = nb & 0xFFFFu;
+        st.c2 = nb >> 16;
+        st.pv = 0; st.want_next = false;
+        disp_l[(size_t)row * W + x] = wta_finish(st, D, dmin, check_unique, one_minus_ratio);
+    }
+}
+
+// ============================================================================================
+// right-view winner-take-all  (ref :374-443 with inverse == 1): cost of right pixel x at disparity d is
+// S[y][x+d][d], 65535 where x+d is off the image (ref :397-408).
+//
+// One lane = one right-view pixel; a workgroup handles WTA_T consecutive pixels of a row and walks the
+// disparity range in chunks of WTA_DC, staging the S columns x0+dmin+dc .. +T+DC-1 through LDS so the
+// diagonal gather reads conflict-free LDS (row stride 33 dwords) instead of strided HBM.  LDS reads are
+// issued 8 at a time so their latency overlaps the compare chain.
+// ============================================================================================
+
+#define WTA_T 256
+#define WTA_DC 64
+#define WTA_LD (WTA_DC + 2)       // u16 row stride (33 dwords: odd, conflict-free lane stride)
+
+__global__ __launch_bounds__(WTA_T) void sgm_wta_right_k(const uint16_t* __restrict__ S, float* __restrict__ disp_r, int W,
+                                                         int H, int D, int Dp, int dmin, int check_unique,
+                                                         float one_minus_ratio)
+{
     __shared__ unsigned short tr[(WTA_T + WTA_DC) * WTA_LD];
     const int row = blockIdx.y;
     const int x0 = blockIdx.x * WTA_T;
@@ -771,46 +846,43 @@ __global__ __launch_bounds__(WTA_T) void sgm_wta_k(const uint16_t* __restrict__ 
     const int x = x0 + i;
     const size_t frame_px = (size_t)blockIdx.z * W * H;                // batch: z = frame
     const uint16_t* Srow = S + (frame_px + (size_t)row * W) * Dp;
-    disp_l += frame_px;
     disp_r += frame_px;
 
-    WtaState sl, sr;
-    sl.m1 = sl.m2 = 0xFFFFu; sl.d1 = -1; sl.c1 = sl.c2 = 0xFFFFu; sl.pv = 0xFFFFu; sl.want_next = false;
-    sr = sl;
+    WtaState sr;
+    sr.m1 = sr.m2 = 0xFFFFu; sr.d1 = -1; sr.c1 = sr.c2 = 0xFFFFu; sr.pv = 0xFFFFu; sr.want_next = false;
 
     for (int dc = 0; dc < D; dc += WTA_DC) {
-        const int nd = min(WTA_DC, D - dc);
         __syncthreads();                                  // previous chunk fully consumed
-        // left tile: pixels x0..x0+T-1, disparities dc..dc+DC-1 (8-element = 16-byte pieces)
-        for (int t = i; t < WTA_T * (WTA_DC / 8); t += WTA_T) {
+        // columns x0+dmin+dc .. +T+DC-2, disparities dc..dc+DC-1 in 16-byte pieces; off-image columns and
+        // disparities >= D read 65535 (ref :407; feeding 65535 never changes the state of a valid result)
+        for (int t = i; t < (WTA_T + WTA_DC) * (WTA_DC / 8); t += WTA_T) {
             const int px = t / (WTA_DC / 8), piece = t % (WTA_DC / 8);
-            const int xx = x0 + px;
+            const int xx = x0 + dmin + dc + px;
+            const int d0 = dc + piece * 8;
             uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-            if (xx < W && dc + piece * 8 < Dp) v = *reinterpret_cast<const uint4*>(Srow + (size_t)xx * Dp + dc + piece * 8);
-            unsigned* dst = reinterpret_cast<unsigned*>(&tl[px * WTA_LD + piece * 8]);
+            if (xx < W && d0 < Dp) {
+                v = *reinterpret_cast<const uint4*>(Srow + (size_t)xx * Dp + d0);
+                if (d0 + 8 > D) {                         // partially / fully padded piece
+                    unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (d0 + k >= D) w[k >> 1] |= (k & 1) ? 0xFFFF0000u : 0x0000FFFFu;
+                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            }
+            unsigned* dst = reinterpret_cast<unsigned*>(&tr[px * WTA_LD + piece * 8]);
             dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
         }
-        if (want_right) {
-            // right tile: columns x0+dmin+dc .. +T+DC-2; off-image columns read 65535 (ref :407)
-            for (int t = i; t < (WTA_T + WTA_DC) * (WTA_DC / 8); t += WTA_T) {
-                const int px = t / (WTA_DC / 8), piece = t % (WTA_DC / 8);
-                const int xx = x0 + dmin + dc + px;
-                uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-                if (xx < W && dc + piece * 8 < Dp) v = *reinterpret_cast<const uint4*>(Srow + (size_t)xx * Dp + dc + piece * 8);
-                unsigned* dst = reinterpret_cast<unsigned*>(&tr[px * WTA_LD + piece * 8]);
-                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-            }
-        }
         __syncthreads();
-        for (int e = 0; e < nd; ++e) {
-            wta_feed(sl, tl[i * WTA_LD + e], dc + e);
-            if (want_right) wta_feed(sr, tr[(i + e) * WTA_LD + e], dc + e);
+        for (int e0 = 0; e0 < WTA_DC; e0 += 8) {
+            unsigned v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = tr[(i + e0 + k) * WTA_LD + e0 + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) wta_feed(sr, v[k], dc + e0 + k);
         }
     }
-    if (x < W) {
-        disp_l[(size_t)row * W + x] = wta_finish(sl, D, dmin, check_unique, one_minus_ratio);
-        if (want_right) disp_r[(size_t)row * W + x] = wta_finish(sr, D, dmin, check_unique, one_minus_ratio);
-    }
+    if (x < W) disp_r[(size_t)row * W + x] = wta_finish(sr, D, dmin, check_unique, one_minus_ratio);
 }
 
 // ============================================================================================
@@ -1245,6 +1317,17 @@ static void launch_aggregate(const AggArgs& a, int blocks, bool pad, hipStream_t
     else     hipLaunchKernelGGL((sgm_aggregate_k<DPL, false, LPP>), dim3(blocks), dim3(64), 0, st, a);
 }
 
+template <int DPL>
+static void launch_sum_wta(dim3 grid, hipStream_t st, const void* planes, size_t plane_bytes, int ndirs, const void* extras,
+                           const void* row_extras, const void* row_extra_count, int row_cap, int accumulate, void* S,
+                           void* disp_l, const sgmd_geom* g, int check_unique, float one_minus_ratio)
+{
+    hipLaunchKernelGGL((sgm_sum_wta_k<DPL>), grid, dim3(256), 0, st, (const uint8_t*)planes, plane_bytes, ndirs,
+                       (const uint8_t*)extras, (const sgmd_row_extra*)row_extras, (const int*)row_extra_count, row_cap,
+                       accumulate, (uint16_t*)S, (float*)disp_l, g->W, g->H, g->D, g->Dp, g->dmin, check_unique,
+                       one_minus_ratio);
+}
+
 extern "C" {
 
 int sgmd_device_count(void)
@@ -1447,27 +1530,37 @@ int sgmd_aggregate(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* 
     return 0;
 }
 
-int sgmd_sum(int ord, void* stream, const sgmd_geom* g, int ndirs, const void* planes, size_t plane_bytes,
-             const void* extras, const void* row_extras, const void* row_extra_count, int row_cap, int accumulate,
-             void* S)
+int sgmd_sum_wta(int ord, void* stream, const sgmd_geom* g, int ndirs, const void* planes, size_t plane_bytes,
+                 const void* extras, const void* row_extras, const void* row_extra_count, int row_cap, int accumulate,
+                 void* S, int check_unique, float one_minus_ratio, void* disp_l)
 {
     HIP_TRY(hipSetDevice(ord));
-    const int per_row = g->W * (g->Dp / 8);
-    dim3 grid((per_row + 255) / 256, g->H, g->B);
-    hipLaunchKernelGGL(sgm_sum_k, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)planes, plane_bytes, ndirs,
-                       (const uint8_t*)extras, (const sgmd_row_extra*)row_extras, (const int*)row_extra_count, row_cap,
-                       accumulate, (uint16_t*)S, g->W, g->H, g->Dp);
+    const dim3 grid((g->W + 15) / 16, g->H, g->B);
+    hipStream_t st = (hipStream_t)stream;
+#define SUM_ARGS grid, st, planes, plane_bytes, ndirs, extras, row_extras, row_extra_count, row_cap, accumulate, S, disp_l, g, check_unique, one_minus_ratio
+    switch (g->Dp / 16) {                                // 16 lanes per pixel here, whatever the aggregation used
+    case 2:  launch_sum_wta<2>(SUM_ARGS); break;
+    case 4:  launch_sum_wta<4>(SUM_ARGS); break;
+    case 8:  launch_sum_wta<8>(SUM_ARGS); break;
+    case 12: launch_sum_wta<12>(SUM_ARGS); break;
+    case 16: launch_sum_wta<16>(SUM_ARGS); break;
+    case 32: launch_sum_wta<32>(SUM_ARGS); break;
+    default:
+        fprintf(stderr, "sgm_mi355x: unsupported Dp %d\n", g->Dp);
+        return -1;
+    }
+#undef SUM_ARGS
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-int sgmd_wta(int ord, void* stream, const sgmd_geom* g, const void* S, int check_unique, float one_minus_ratio,
-             int want_right, void* disp_l, void* disp_r)
+int sgmd_wta_right(int ord, void* stream, const sgmd_geom* g, const void* S, int check_unique, float one_minus_ratio,
+                   void* disp_r)
 {
     HIP_TRY(hipSetDevice(ord));
     dim3 grid((g->W + WTA_T - 1) / WTA_T, g->H, g->B);
-    hipLaunchKernelGGL(sgm_wta_k, grid, dim3(WTA_T), 0, (hipStream_t)stream, (const uint16_t*)S, (float*)disp_l,
-                       (float*)disp_r, g->W, g->H, g->D, g->Dp, g->dmin, check_unique, one_minus_ratio, want_right);
+    hipLaunchKernelGGL(sgm_wta_right_k, grid, dim3(WTA_T), 0, (hipStream_t)stream, (const uint16_t*)S, (float*)disp_r,
+                       g->W, g->H, g->D, g->Dp, g->dmin, check_unique, one_minus_ratio);
     HIP_TRY(hipGetLastError());
     return 0;
 }
