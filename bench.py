@@ -197,10 +197,14 @@ def main():
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                         "traffic": None, "avg_launch_ms": round(agg_ms, 4),
                         "algorithmic_bytes_per_launch": agg_bytes}
+            # HBM bytes of this kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, measured at
+            # one frame per launch, see profiles/hbm_traffic.json), scaled to the B frames of a launch
             prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if os.path.exists(prof):
                 with open(prof) as f:
-                    roofline["traffic"] = json.load(f).get(args.workload, {}).get("sgm_aggregate_k")
+                    per_frame = json.load(f).get(args.workload, {}).get("sgm_aggregate_k")
+                if per_frame:
+                    roofline["traffic"] = int(per_frame) * B
         frame_bytes = cells * (5 * PATHS + 3)
         steps_frames = args.steps * B
         line = {
