@@ -208,3 +208,28 @@ def test_batched_frames_one_launch_per_stage(oracle):
                 assert_same(got[n], want[n], f"batch {w}x{h} frame {k}: {n}")
             assert_same(out[k], want["final"], f"batch {w}x{h} frame {k}: result")
         inst.close()
+
+
+def _corner_cases():
+    from test_oracle_vs_reference import _cases
+    return _cases()
+
+
+@pytest.mark.parametrize("case", _corner_cases(), ids=lambda c: f"{c[0]}x{c[1]}_d{c[2]}-{c[3]}_s{c[4]}")
+def test_random_options_and_degenerate_shapes(inst, oracle, case):
+    """The option / shape sweep the oracle is pinned on against the reference (test_oracle_vs_reference.py), incl.
+    one-row / one-column images, 2x2, census no-op sizes, D = 1, negative and huge penalties."""
+    w, h, dmin, dmax, seed, kw = case
+    from oracle.pyoracle import default_option
+    left, right = oracle.synth_pair(w, h, dmax - dmin, seed)
+    opt = default_option(dmax, dmin, **kw)
+    want = oracle.run(left, right, opt)
+    assert inst.reset(w, h, opt)
+    out = inst.match(left, right)
+    assert out is not None
+    got = inst.read_stages()
+    for n in STAGE_NAMES:
+        if n == "disp_r" and not opt.is_check_lr:
+            continue
+        assert_same(got[n], want[n], f"{case}:{n}")
+    assert_same(out, want["final"], f"{case}:result")

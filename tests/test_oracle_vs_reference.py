@@ -1,0 +1,61 @@
+"""Our CPU restatement against the reference's own C (oracle/_ref, built by oracle/build_ref.sh) on seeded
+random shapes and options -- every stage.  Skipped where the reference build is absent (the golden
+fixtures of test_oracle_golden.py carry the same pin without it)."""
+import numpy as np
+import pytest
+
+from oracle.pyoracle import DIRECTIONS, STAGE_NAMES, Reference, default_option, ref_path
+
+pytestmark = pytest.mark.skipif(ref_path(24, 16, 8) is None, reason="oracle/_ref not built (needs /root/reference)")
+
+
+def _cases():
+    rng = np.random.RandomState(20261004)
+    out = []
+    for k in range(28):
+        w = int(rng.randint(6, 120))
+        h = int(rng.randint(6, 70))
+        d = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 31, 32, 47, 64]))
+        dmin = int(rng.choice([0, 0, 0, 1, 4, 9]))
+        kw = dict(p1=int(rng.choice([0, 3, 10, 25, 90])), p2_init=int(rng.choice([0, 8, 150, 255, 1000])),
+                  is_check_unique=bool(rng.rand() < 0.8), uniqueness_ratio=float(rng.choice([0.99, 0.95, 0.5, 1.0])),
+                  is_check_lr=bool(rng.rand() < 0.8), lrcheck_thres=float(rng.choice([1.0, 0.0, 2.5])),
+                  is_remove_speckles=bool(rng.rand() < 0.8), min_speckle_area=int(rng.choice([0, 1, 7, 50])))
+        if dmin > 0 and kw["is_check_lr"] and not kw["is_check_unique"]:
+            # the reference reads cost_local[65535 - dmin] here (right-view pixel with no in-image candidate,
+            # SemiGlobalMatching.c:432-435) and segfaults: undefined behaviour, not a parity target
+            kw["is_check_unique"] = True
+        out.append((w, h, dmin, dmin + d, 1000 + k, kw))
+    # hand-picked corners: negative penalties, the census no-op sizes, one-row / one-column images
+    out += [(40, 20, 0, 16, 1, dict(p1=-7, p2_init=120)), (40, 20, 0, 16, 2, dict(p1=12, p2_init=-300)),
+            (40, 20, 0, 16, 3, dict(p1=32767, p2_init=32767)), (5, 30, 0, 4, 4, {}), (30, 5, 0, 4, 5, {}),
+            (1, 9, 0, 2, 6, {}), (9, 1, 0, 2, 7, {}), (2, 2, 0, 1, 8, {}), (3, 40, 0, 2, 9, {}),
+            (64, 3, 0, 8, 10, dict(min_speckle_area=3))]
+    return out
+
+
+@pytest.mark.parametrize("case", _cases(), ids=lambda c: f"{c[0]}x{c[1]}_d{c[2]}-{c[3]}_s{c[4]}")
+def test_all_stages_equal_reference(oracle, case):
+    w, h, dmin, dmax, seed, kw = case
+    left, right = oracle.synth_pair(w, h, dmax - dmin, seed)
+    opt = default_option(dmax, dmin, **kw)
+    ref = Reference.for_shape(w, h, dmax - dmin)
+    want = ref.run(left, right, opt)
+    got = oracle.run(left, right, opt)
+    if not opt.is_check_lr:
+        got["disp_r"][:] = 0
+    for n in STAGE_NAMES:
+        a, b = got[n], want[n]
+        same = np.array_equal(a.view(np.uint32), b.view(np.uint32)) if a.dtype == np.float32 else np.array_equal(a, b)
+        assert same, f"{case}: stage {n} differs"
+
+
+def test_per_direction_aggregation_equal_reference(oracle):
+    for (w, h, d, seed) in [(23, 17, 6, 1), (17, 23, 6, 2), (64, 9, 20, 3)]:
+        left, right = oracle.synth_pair(w, h, d, seed)
+        opt = default_option(d)
+        ref = Reference.for_shape(w, h, d)
+        cost = ref.run(left, right, opt)["cost"]
+        for dx, dy in DIRECTIONS:
+            S, _, _ = oracle.aggregate_dir(left, cost, opt.p1, opt.p2_init, dx, dy)
+            np.testing.assert_array_equal(S, ref.aggregate_dir(left, cost, opt, dx, dy), err_msg=f"{(w, h, dx, dy)}")
