@@ -1,0 +1,58 @@
+"""Image I/O of the C command-line driver (no GPU): PNG / PPM / PGM decode to the grey stb_image produces for the
+reference's main.c ((77 r + 150 g + 29 b) >> 8), and the PNG writer round-trips."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+EXE = os.path.join(ROOT, "soc_project_stereo_matching_amd", "sgm_main")
+
+
+def luma(rgb):
+    a = rgb.astype(np.uint32)
+    return ((a[..., 0] * 77 + a[..., 1] * 150 + a[..., 2] * 29) >> 8).astype(np.uint8)
+
+
+@pytest.fixture(scope="module")
+def exe():
+    if not os.path.exists(EXE):
+        import __graft_entry__
+        __graft_entry__.build()
+    return EXE
+
+
+def test_decoders_and_png_writer(exe, tmp_path):
+    from PIL import Image
+    rng = np.random.RandomState(1)
+    rgb = rng.randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    rgb[:, :20] = (rgb[:, :20] // 32) * 32               # flat areas so every PNG filter type gets used
+    want = luma(rgb)
+    alpha = rng.randint(0, 256, (37, 53, 1)).astype(np.uint8)
+    pal = Image.fromarray(rgb).quantize(200)
+    files = {"rgb.png": (Image.fromarray(rgb), want), "rgba.png": (Image.fromarray(np.dstack([rgb, alpha])), want),
+             "gray.png": (Image.fromarray(want), want), "ga.png": (Image.fromarray(np.dstack([want, alpha[..., 0]]), "LA"), want),
+             "pal.png": (pal, luma(np.asarray(pal.convert("RGB")))), "rgb.ppm": (Image.fromarray(rgb), want),
+             "gray.pgm": (Image.fromarray(want), want)}
+    for name, (im, expect) in files.items():
+        src = str(tmp_path / name)
+        im.save(src)
+        for ext in ("png", "pgm"):
+            dst = str(tmp_path / f"out_{name}.{ext}")
+            subprocess.check_call([exe, "--convert", src, dst])
+            got = np.asarray(Image.open(dst))
+            assert np.array_equal(got, expect), (name, ext)
+
+
+def test_rejects_what_it_cannot_read(exe, tmp_path):
+    from PIL import Image
+    bad = str(tmp_path / "bad.png")
+    open(bad, "wb").write(b"not a png at all")
+    assert subprocess.call([exe, "--convert", bad, str(tmp_path / "o.png")], stderr=subprocess.DEVNULL) != 0
+    im16 = str(tmp_path / "deep.png")
+    Image.fromarray((np.arange(64, dtype=np.uint16) * 900).reshape(8, 8)).save(im16)     # 16-bit grey: unsupported
+    assert subprocess.call([exe, "--convert", im16, str(tmp_path / "o.png")], stderr=subprocess.DEVNULL) != 0
+    assert subprocess.call([exe, "--convert", str(tmp_path / "missing.png"), str(tmp_path / "o.png")],
+                           stderr=subprocess.DEVNULL) != 0

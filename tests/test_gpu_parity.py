@@ -233,3 +233,23 @@ def test_random_options_and_degenerate_shapes(inst, oracle, case):
             continue
         assert_same(got[n], want[n], f"{case}:{n}")
     assert_same(out, want["final"], f"{case}:result")
+
+
+def test_c_driver_reproduces_the_reference_fixture(tmp_path):
+    """soc_project_stereo_matching_amd/sgm_main = the reference's main.c flow in C (load -> SGM_Initialize ->
+    SGM_Match -> normalise -> PNG).  On the cone pair its PNG equals the reference's committed
+    Data/cone/im2.d.png except the one pixel of SURVEY.md Q6, and its raw disparities equal the golden floats."""
+    import os
+    import subprocess
+    from PIL import Image
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "soc_project_stereo_matching_amd", "sgm_main")
+    z = load_npz("cone_inputs.npz")
+    Image.fromarray(z["left"]).save(str(tmp_path / "im2.pgm"))
+    Image.fromarray(z["right"]).save(str(tmp_path / "im6.png"))          # one PGM, one PNG: both readers
+    out_png, out_raw = str(tmp_path / "im2.d.png"), str(tmp_path / "im2.d.f32")
+    subprocess.check_call([exe, str(tmp_path / "im2.pgm"), str(tmp_path / "im6.png"), out_png, "--raw", out_raw])
+    got = np.asarray(Image.open(out_png))
+    assert np.argwhere(got != z["im2_d_png"]).tolist() == [[374, 153]]
+    raw = np.fromfile(out_raw, np.float32).reshape(375, 450)
+    assert_same(raw, load_npz("cone_final.npz")["final"], "driver raw disparities")
