@@ -151,6 +151,24 @@ def main():
     np.savez_compressed(os.path.join(OUT, "q14_no_reset_48x20_d16.npz"), left=l, right=r, left2=l2, right2=r2,
                         first=first, second=second, second_fresh=second_fresh)
 
+    # ---- test-platform calibration block: produced by the reference's own
+    # HostScript_Server/stereo_calibration.py (numpy only; imported here, never shipped) ----
+    sys.path.insert(0, "/root/reference/HostScript_Server")
+    import stereo_calibration                      # noqa: E402  (reference module, build container only)
+    calib_txt = ("cam0=[1733.74 0 792.27; 0 1733.74 541.89; 0 0 1]\n"
+                 "cam1=[1733.74 0 792.27; 0 1733.74 541.89; 0 0 1]\n"
+                 "doffs=0\nbaseline=536.62\nwidth=1920\nheight=1080\nndisp=170\n")
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as tf:
+        tf.write(calib_txt)
+    cal = stereo_calibration.StereoCalib(tf.name)
+    cal.scale_calib(1280, 720)
+    packed = np.frombuffer(cal.pack(), np.uint8).copy()
+    os.unlink(tf.name)
+    np.savez_compressed(os.path.join(OUT, "platform_calib.npz"), calib_txt=np.frombuffer(calib_txt.encode(), np.uint8),
+                        packed=packed, fx=np.float64(cal.cam0[0, 0]), doffs=np.float64(cal.doffs),
+                        baseline=np.float64(cal.baseline))
+
     with open(os.path.join(OUT, "cases.json"), "w") as f:
         json.dump({"generator": "tests/golden/make_golden.py", "source": "oracle/_ref (reference C, guarded build)",
                    "cases": cases}, f, indent=1)
