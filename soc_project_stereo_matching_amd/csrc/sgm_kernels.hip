@@ -955,52 +955,79 @@ static __device__ __forceinline__ bool spk_linked(float u, float v, float diff)
 
 // (A) label[p] = global pixel index of the tile-local root (or -1 for invalid pixels);
 //     local_size[p] = pixel count of the tile-local component for roots, 0 elsewhere; total[p] = 0
+// A tile row is exactly one wave (64 px): horizontal runs are labelled with a wave prefix-max (no atomics), so the
+// union-find only has to join RUNS of adjacent rows, and only where the link is not already implied by the
+// pixel to the left -- a flat 64x16 tile needs ~16 unions instead of ~3000 on contended roots.
 __global__ __launch_bounds__(256) void sgm_speckle_tile_k(const float* __restrict__ disp, int* __restrict__ label,
                                                           int* __restrict__ local_size, int* __restrict__ total, int W,
                                                           int H, float diff)
 {
+    static_assert(SPK_TW == 64, "one tile row = one wave");
     __shared__ float tile[SPK_N];
     __shared__ int lab[SPK_N];
     __shared__ int cnt[SPK_N];
+    __shared__ unsigned char left_link[SPK_N];             // pixel linked to its left neighbour (same run)
     const int tx0 = blockIdx.x * SPK_TW, ty0 = blockIdx.y * SPK_TH;
     const float inf = __builtin_inff();
     {
         const size_t frame_px = (size_t)blockIdx.z * W * H;            // batch: z = frame (labels are per-frame pixel indices)
         disp += frame_px; label += frame_px; local_size += frame_px; total += frame_px;
     }
-    for (int i = threadIdx.x; i < SPK_N; i += 256) {
-        const int x = tx0 + (i & (SPK_TW - 1)), y = ty0 + (i / SPK_TW);
+    const int lx = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // ---- rows wv, wv+4, ...: load, link to the left, label runs with their first pixel ----
+    for (int ly = wv; ly < SPK_TH; ly += 4) {
+        const int i = ly * SPK_TW + lx;
+        const int x = tx0 + lx, y = ty0 + ly;
         const float v = (x < W && y < H) ? disp[(size_t)y * W + x] : inf;
+        const float vl = __shfl_up(v, 1);
+        const bool linkl = lx > 0 && spk_linked(vl, v, diff);
+        int start = linkl ? -1 : lx;                       // run starts where the link to the left is broken
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {                 // inclusive prefix max over the wave
+            const int o = __shfl_up(start, d);
+            if (lx >= d) start = max(start, o);
+        }
         tile[i] = v;
-        lab[i] = (v == inf) ? -1 : i;
+        left_link[i] = linkl ? 1 : 0;
+        lab[i] = (v == inf) ? -1 : ly * SPK_TW + start;
         cnt[i] = 0;
     }
     __syncthreads();
+    // ---- join runs of adjacent rows ----
     for (int i = threadIdx.x; i < SPK_N; i += 256) {
         const float v = tile[i];
-        if (v == inf) continue;
-        const int lx = i & (SPK_TW - 1), ly = i / SPK_TW;
-        // the four already-scanned neighbours cover every 8-neighbour edge once
-        if (lx > 0 && spk_linked(tile[i - 1], v, diff)) uf_union(lab, i, i - 1);
-        if (ly > 0) {
-            if (spk_linked(tile[i - SPK_TW], v, diff)) uf_union(lab, i, i - SPK_TW);
-            if (lx > 0 && spk_linked(tile[i - SPK_TW - 1], v, diff)) uf_union(lab, i, i - SPK_TW - 1);
-            if (lx < SPK_TW - 1 && spk_linked(tile[i - SPK_TW + 1], v, diff)) uf_union(lab, i, i - SPK_TW + 1);
+        const int ly = i / SPK_TW;
+        if (v == inf || ly == 0) continue;
+        const int up = i - SPK_TW;
+        const bool l_up = spk_linked(tile[up], v, diff);
+        // (x,y)-(x,y-1): already joined by the pixel to the left if both rows continue their runs there and
+        // the left pair is linked as well
+        if (l_up) {
+            const bool implied = lx > 0 && left_link[i] && left_link[up] && spk_linked(tile[up - 1], tile[i - 1], diff);
+            if (!implied) uf_union(lab, lab[i], lab[up]);
+        }
+        // diagonals: implied when the pixel straight above is linked to us and continues into the diagonal one
+        if (lx > 0 && spk_linked(tile[up - 1], v, diff) && !(l_up && left_link[up])) uf_union(lab, lab[i], lab[up - 1]);
+        if (lx < SPK_TW - 1 && spk_linked(tile[up + 1], v, diff) && !(l_up && left_link[up + 1])) uf_union(lab, lab[i], lab[up + 1]);
+    }
+    __syncthreads();
+    // ---- pixel counts per tile-local root: one LDS atomic per run (its last pixel knows the run length) ----
+    for (int i = threadIdx.x; i < SPK_N; i += 256) {
+        if (lab[i] < 0) continue;
+        const bool last_of_run = (lx == SPK_TW - 1) || !left_link[i + 1];
+        if (last_of_run) {
+            const int first = left_link[i] ? lab[i] : i;   // entries of non-first pixels still name the run's first pixel
+            atomicAdd(&cnt[uf_find(lab, first)], i - first + 1);
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < SPK_N; i += 256) {
-        if (lab[i] < 0) continue;
-        atomicAdd(&cnt[uf_find(lab, i)], 1);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < SPK_N; i += 256) {
-        const int x = tx0 + (i & (SPK_TW - 1)), y = ty0 + (i / SPK_TW);
+        const int x = tx0 + lx, y = ty0 + (i / SPK_TW);
         if (x >= W || y >= H) continue;
         const size_t p = (size_t)y * W + x;
         int g = -1;
         if (lab[i] >= 0) {
-            const int r = uf_find(lab, i);
+            const int r = uf_find(lab, lab[i]);
             g = (ty0 + r / SPK_TW) * W + tx0 + (r & (SPK_TW - 1));
         }
         label[p] = g;
