@@ -326,12 +326,20 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
     s->g.DPL = pick_dpl(D);
     s->g.LPP = 16;
     s->g.Dp = 16 * s->g.DPL;
-    /* a batch of frames is VALU-bound: 8 lanes per pixel (twice the disparities per lane, same Dp) spends
-     * fewer instructions per cell; a single frame keeps 16 lanes per pixel for the shorter serial step */
+    /* a batch of frames is VALU-bound: 8 lanes per pixel (twice the disparities per lane, same Dp) spends the
+     * fewest instructions per cell; a single frame keeps 16 lanes per pixel for the shorter serial step (measured
+     * at KITTI size, one frame: 16 lanes + H32 0.34 ms, 8 lanes + H32 0.39 ms, 8 lanes 0.59 ms) */
     {
         const char* e = getenv("SGM_LANES_PER_PIXEL");
         const int want = (e && *e) ? atoi(e) : (s->batch >= 2 ? 8 : 16);
         if (want == 8 && s->g.DPL >= 2 && s->g.DPL <= 8 && s->g.DPL != 6) { s->g.LPP = 8; s->g.DPL *= 2; }
+    }
+    /* one frame per launch: the horizontal lines (W-1 serial steps) are the critical path -> 32 lanes per pixel for them */
+    {
+        const char* e = getenv("SGM_H32");
+        const int per = s->g.Dp / 32;
+        const int can = (s->g.Dp % 32 == 0) && (per == 2 || per == 4 || per == 8 || per == 16);
+        s->g.H32 = can && ((e && *e) ? atoi(e) != 0 : s->batch == 1);
     }
     s->g.dmin = option->min_disparity;
     s->g.B = s->batch;

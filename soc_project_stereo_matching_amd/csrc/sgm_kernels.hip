@@ -69,7 +69,11 @@ static __device__ __forceinline__ unsigned row_allmin(unsigned v)
     v = min(v, dpp_perm<DPP_QUAD_XOR1>(v));
     v = min(v, dpp_perm<DPP_QUAD_XOR2>(v));
     v = min(v, dpp_perm<DPP_ROW_HALF_MIRROR>(v));                 // all 8 lanes of a half row agree
-    if (LPP == 16) v = min(v, dpp_perm<DPP_ROW_MIRROR>(v));       // all 16 lanes of the row agree
+    if (LPP >= 16) v = min(v, dpp_perm<DPP_ROW_MIRROR>(v));       // all 16 lanes of the row agree
+    if (LPP == 32) {                                              // rows 0|1 and 2|3: v_permlane16_swap exchanges them
+        const auto sw = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        v = min(sw[0], sw[1]);
+    }
     return v;
 }
 
@@ -342,9 +346,15 @@ static __device__ __forceinline__ unsigned agg_step(const us2 (&C)[DPL / 2], us2
     const us2 l4 = as_p(l4u | (l4u << 16));
     const us2 mp = as_p(min_prev | (min_prev << 16));
     // d-1 / d+1 neighbours across the lane boundary; 255 where there is none (ref :260-263)
-    unsigned from_left = dpp_mov<DPP_ROW_SHR1>(0x00FF00FFu, as_u(Lp[NP - 1]));
-    unsigned from_right = dpp_mov<DPP_ROW_SHL1>(0x00FF00FFu, as_u(Lp[0]));
-    if (LPP == 8) {                                     // two pixels share a 16-lane DPP row: cut the shift between them
+    unsigned from_left, from_right;
+    if (LPP == 32) {                                    // a pixel spans two DPP rows: shift across the whole wave
+        from_left = dpp_mov<0x138 /* wave_shr:1 */>(0x00FF00FFu, as_u(Lp[NP - 1]));
+        from_right = dpp_mov<0x130 /* wave_shl:1 */>(0x00FF00FFu, as_u(Lp[0]));
+    } else {
+        from_left = dpp_mov<DPP_ROW_SHR1>(0x00FF00FFu, as_u(Lp[NP - 1]));
+        from_right = dpp_mov<DPP_ROW_SHL1>(0x00FF00FFu, as_u(Lp[0]));
+    }
+    if (LPP != 16) {                                    // pixel boundaries that are not DPP row boundaries: cut the shift there
         from_left = first_lane ? 0x00FF00FFu : from_left;
         from_right = last_lane ? 0x00FF00FFu : from_right;
     }
@@ -383,7 +393,7 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
                                                    int dir, int grp)
 {
     constexpr int NP = DPL / 2;
-    constexpr int PF = 2;                                                  // software prefetch depth (steps); 2 keeps DPL=8 at 56 VGPRs = 8 waves/SIMD
+    constexpr int PF = (LPP == 32) ? 4 : 2;                              // prefetch depth (steps): 2 keeps the 8-lines-per-wave kernel at 8 waves/SIMD; the latency-critical 32-lane lines look further ahead
     const int lane = threadIdx.x;
     const int dx = a.dx[dir], dy = a.dy[dir];
     const int W = a.W, H = a.H, Dp = a.Dp;
@@ -648,7 +658,7 @@ static __device__ __forceinline__ void agg_anomalous(const AggArgs& a, const Agg
     }
 }
 
-template <int DPL, bool PAD, int LPP>
+template <int DPL, bool PAD, int LPP, bool H32>
 __global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
 {
     __shared__ unsigned short lut_s[256];
@@ -678,7 +688,13 @@ __global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
     // the horizontal lines are the longest serial chains of the launch (W-1 dependent steps): their waves
     // get issue priority over the shorter vertical/diagonal ones sharing the SIMD, also across frames in flight
     if (a.dy[dir] == 0) __builtin_amdgcn_s_setprio(3);
-    if (a.dy[dir] == 0)      agg_regular<DPL, PAD, LPP, AGG_H>(a, fr, lut_s, dir, grp);
+    // H32 (single-frame mode): the horizontal lines are the critical path of the launch (W-1 serial steps), so
+    // they get 32 lanes per pixel -- fewer disparities per lane, the shortest step -- while the vertical and
+    // diagonal lines keep the lane count that costs the fewest instructions per cell
+    if (a.dy[dir] == 0) {
+        if constexpr (H32) agg_regular<DPL * LPP / 32, PAD, 32, AGG_H>(a, fr, lut_s, dir, grp);
+        else               agg_regular<DPL, PAD, LPP, AGG_H>(a, fr, lut_s, dir, grp);
+    }
     else if (a.dx[dir] == 0) agg_regular<DPL, PAD, LPP, AGG_V>(a, fr, lut_s, dir, grp);
     else                     agg_regular<DPL, PAD, LPP, AGG_D>(a, fr, lut_s, dir, grp);
 }
@@ -1338,10 +1354,19 @@ extern "C" size_t sgmd_census_slack(const sgmd_geom* g)
 }
 
 template <int DPL, int LPP>
-static void launch_aggregate(const AggArgs& a, int blocks, bool pad, hipStream_t st)
+static void launch_aggregate(const AggArgs& a, int blocks, bool pad, bool h32, hipStream_t st)
 {
-    if (pad) hipLaunchKernelGGL((sgm_aggregate_k<DPL, true, LPP>), dim3(blocks), dim3(64), 0, st, a);
-    else     hipLaunchKernelGGL((sgm_aggregate_k<DPL, false, LPP>), dim3(blocks), dim3(64), 0, st, a);
+    constexpr bool can_h32 = (DPL * LPP / 32 == 2 || DPL * LPP / 32 == 4 || DPL * LPP / 32 == 8 || DPL * LPP / 32 == 16) &&
+                             (DPL * LPP % 32 == 0);
+    if constexpr (can_h32) {
+        if (h32) {
+            if (pad) hipLaunchKernelGGL((sgm_aggregate_k<DPL, true, LPP, true>), dim3(blocks), dim3(64), 0, st, a);
+            else     hipLaunchKernelGGL((sgm_aggregate_k<DPL, false, LPP, true>), dim3(blocks), dim3(64), 0, st, a);
+            return;
+        }
+    }
+    if (pad) hipLaunchKernelGGL((sgm_aggregate_k<DPL, true, LPP, false>), dim3(blocks), dim3(64), 0, st, a);
+    else     hipLaunchKernelGGL((sgm_aggregate_k<DPL, false, LPP, false>), dim3(blocks), dim3(64), 0, st, a);
 }
 
 template <int DPL>
@@ -1526,7 +1551,7 @@ int sgmd_aggregate(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* 
         a.block_begin[d] = blocks;
         if (d < paths->ndirs) {
             const int nlines = (paths->dy[d] == 0) ? g->H : g->W;
-            const int lines_per_wave = 64 / g->LPP;
+            const int lines_per_wave = (paths->dy[d] == 0 && g->H32) ? 2 : 64 / g->LPP;
             blocks += (nlines + lines_per_wave - 1) / lines_per_wave;
         }
     }
@@ -1540,15 +1565,15 @@ int sgmd_aggregate(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* 
     // per cell and is what a batch of frames (VALU-bound) uses.
     const int key = g->LPP * 100 + g->DPL;
     switch (key) {
-    case 1602: launch_aggregate<2, 16>(a, blocks, pad, st); break;
-    case 1604: launch_aggregate<4, 16>(a, blocks, pad, st); break;
-    case 1608: launch_aggregate<8, 16>(a, blocks, pad, st); break;
-    case 1612: launch_aggregate<12, 16>(a, blocks, pad, st); break;
-    case 1616: launch_aggregate<16, 16>(a, blocks, pad, st); break;
-    case 1632: launch_aggregate<32, 16>(a, blocks, pad, st); break;
-    case 804:  launch_aggregate<4, 8>(a, blocks, pad, st); break;
-    case 808:  launch_aggregate<8, 8>(a, blocks, pad, st); break;
-    case 816:  launch_aggregate<16, 8>(a, blocks, pad, st); break;
+    case 1602: launch_aggregate<2, 16>(a, blocks, pad, g->H32 != 0, st); break;
+    case 1604: launch_aggregate<4, 16>(a, blocks, pad, g->H32 != 0, st); break;
+    case 1608: launch_aggregate<8, 16>(a, blocks, pad, g->H32 != 0, st); break;
+    case 1612: launch_aggregate<12, 16>(a, blocks, pad, g->H32 != 0, st); break;
+    case 1616: launch_aggregate<16, 16>(a, blocks, pad, g->H32 != 0, st); break;
+    case 1632: launch_aggregate<32, 16>(a, blocks, pad, g->H32 != 0, st); break;
+    case 804:  launch_aggregate<4, 8>(a, blocks, pad, g->H32 != 0, st); break;
+    case 808:  launch_aggregate<8, 8>(a, blocks, pad, g->H32 != 0, st); break;
+    case 816:  launch_aggregate<16, 8>(a, blocks, pad, g->H32 != 0, st); break;
     default:
         fprintf(stderr, "sgm_mi355x: unsupported lanes-per-pixel/DPL combination %d/%d\n", g->LPP, g->DPL);
         return -1;
