@@ -266,16 +266,7 @@ static __device__ __forceinline__ void store_cells(uint8_t* p, const CellVec<DPL
     }
 }
 
-// bytes -> packed u16 pairs and back (v_perm_b32)
-template <int DPL>
-static __device__ __forceinline__ void unpack_cells(const CellVec<DPL>& v, us2 (&pr)[DPL / 2])
-{
-#pragma unroll
-    for (int j = 0; j < DPL / 2; ++j) {
-        const unsigned w = v.w[j >> 1];
-        pr[j] = as_p(__builtin_amdgcn_perm(w, w, (j & 1) ? 0x0c030c02u : 0x0c010c00u));
-    }
-}
+// packed u16 pairs -> bytes (v_perm_b32)
 template <int DPL>
 static __device__ __forceinline__ void pack_cells(const us2 (&pr)[DPL / 2], CellVec<DPL>& v)
 {

@@ -80,7 +80,8 @@ def test_cone_through_reference_entry_points(gsgm, oracle, golden_cases):
 
 
 @pytest.mark.parametrize("shape", [(37, 21, 0, 8), (15, 29, 0, 8), (130, 47, 2, 50), (257, 64, 0, 100), (64, 7, 0, 16),
-                                   (9, 9, 0, 4), (40, 1100, 0, 8), (600, 300, 0, 256), (520, 40, 0, 512)])
+                                   (9, 9, 0, 4), (40, 1100, 0, 8), (600, 300, 0, 256), (520, 40, 0, 512),
+                                   (1762, 120, 0, 192), (2880, 90, 0, 256)])    # full widths of configs 4 and 2
 def test_random_shapes_against_oracle(inst, oracle, shape):
     """Seeded shapes incl. W<H, H > one median band (1024 rows), odd D, the largest D."""
     w, h, dmin, dmax = shape
