@@ -113,6 +113,31 @@ bool          sgm_set_batch(sgm_instance* s, int frames);
 /* which frame of the batch sgm_read_stage returns (default 0) */
 void          sgm_select_frame(sgm_instance* s, int frame);
 
+/* ---- row tiles: one frame over several GPUs (each GPU one instance, one process per GPU) ----
+ * After sgm_set_rows(s, r0, r1) and the next sgm_initialize / sgm_reset the instance computes rows [r0, r1) of
+ * the frame (r1 = 0 returns to whole frames).  Per frame, on every GPU (all calls asynchronous on sgm_stream):
+ *
+ *     sgm_tile_begin(s, d_left, d_right)          census, horizontal paths of the tile, anomalous diagonals
+ *     forward sweep, tiles top to bottom:          backward sweep, tiles bottom to top:
+ *       [sgm_tile_import_boundary(s, 1, buf)]        [sgm_tile_import_boundary(s, 0, buf)]   not at the frame edge
+ *       sgm_tile_sweep(s, 1)                         sgm_tile_sweep(s, 0)
+ *       sgm_tile_export_boundary(s, 1, buf)          sgm_tile_export_boundary(s, 0, buf)     -> next GPU
+ *     sgm_tile_finish(s, d_disp)                   cost sum, WTA (both views), LR check -> rows [r0, r1) of d_disp
+ *     (gather the rows of all GPUs into one [H][W] map)
+ *     sgm_tile_post(s, d_disp)                     speckle removal + median on the whole frame
+ *
+ * d_left / d_right are the whole images (replicated); buf holds sgm_tile_boundary_bytes(s) bytes of device
+ * memory: the path costs of one image row for the 3 directions of a sweep (1 with four paths).  The two
+ * sweeps are independent of each other.  The result is bit-identical to sgm_match on one GPU. */
+bool   sgm_set_rows(sgm_instance* s, int row_begin, int row_end);
+bool   sgm_tile_begin(sgm_instance* s, const uint8_t* d_left, const uint8_t* d_right);
+size_t sgm_tile_boundary_bytes(const sgm_instance* s);
+bool   sgm_tile_import_boundary(sgm_instance* s, int forward, const void* d_buf);
+bool   sgm_tile_sweep(sgm_instance* s, int forward);
+bool   sgm_tile_export_boundary(sgm_instance* s, int forward, void* d_buf);
+bool   sgm_tile_finish(sgm_instance* s, float* d_disp_left);
+bool   sgm_tile_post(sgm_instance* s, float* d_disp_left);
+
 /* ---- stage read-back (parity tests; copies device -> host, blocking) ----
  * which: 0 census left (u32 [H][W])       1 census right (u32 [H][W])
  *        2 matching cost (u8 [H][W][D])   3 aggregated cost S (u16 [H][W][D])

@@ -46,6 +46,8 @@ typedef struct {
     int dmin;          /* min_disparity */
     int B;             /* frames per launch (batch): every buffer is [B][...] frame-major, every kernel
                           processes all B frames */
+    int row_begin, row_end;  /* the rows this GPU computes in aggregate / sum_wta / wta_right / lrcheck: [0,H) normally,
+                          a row tile when a frame is spread over several GPUs (buffers stay frame-sized) */
 } sgmd_geom;
 
 /* one anomalous-line visit that lands on a pixel of row `row` (built by the host) */
@@ -60,6 +62,8 @@ typedef struct {
     int anom_line[8];          /* line index whose first step trips the wrong edge test, or -1 */
     int ghost_zero;            /* 1: W >= H, the anomalous wave zeroes the cells no line visits */
     int p1;
+    int dir_mask;              /* bit d: run direction d in this launch (0xFF normally; a tile sweep runs a subset) */
+    int run_anom;              /* 1: run the anomalous diagonal lines in this launch (whole frame, never tiled) */
 } sgmd_paths;
 
 /* ---- stage launchers (all asynchronous on `stream`) ---- */

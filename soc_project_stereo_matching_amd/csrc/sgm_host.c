@@ -37,6 +37,8 @@ struct sgm_instance {
     int honor_num_paths;
     int batch;                   /* frames per match call (>= 1); takes effect at the next initialize */
     int read_frame;              /* which frame of the batch sgm_read_stage returns */
+    int tile_begin, tile_end;    /* row tile this instance computes (sgm_set_rows); tile_end == 0: the whole frame */
+    const void* tile_left;       /* left image of the frame a tile sequence is working on */
 
     bool initialized;
     bool s_is_zero;              /* aggregated-cost volume logically zero (set by Initialize/Reset, Q14) */
@@ -343,6 +345,14 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
     }
     s->g.dmin = option->min_disparity;
     s->g.B = s->batch;
+    s->g.row_begin = 0; s->g.row_end = height;
+    if (s->tile_end != 0) {
+        if (s->tile_begin < 0 || s->tile_begin >= s->tile_end || s->tile_end > height)
+            FAIL("row tile [%d,%d) does not fit a frame of %d rows", s->tile_begin, s->tile_end, height);
+        if (s->batch != 1) FAIL("row tiles need batch == 1");
+        s->g.row_begin = s->tile_begin; s->g.row_end = s->tile_end;
+    }
+    s->tile_left = NULL;
     if (s->read_frame >= s->batch) s->read_frame = 0;
     if ((unsigned long long)width * height * (unsigned)s->g.Dp >= 0xFFFFFFFFull)
         FAIL("cost volume too large: width*height*%d must stay below 2^32 cells (32-bit offsets in the kernels)", s->g.Dp);
@@ -355,6 +365,8 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
         s->paths.anom_line[d] = (d >= 4) ? anomalous_line(width, k_dir_dx[d]) : -1;
     }
     s->paths.ghost_zero = (width >= height);
+    s->paths.dir_mask = 0xFF;
+    s->paths.run_anom = 1;
     s->need_plane_memset = !s->paths.ghost_zero;
 
     if (!ensure_buffers(s)) return false;
@@ -448,6 +460,125 @@ static bool run_pipeline(sgm_instance* s, const void* d_left, const void* d_righ
     return true;
 }
 
+/* ------------------------------------------------------------------ row tiles (one frame over several GPUs)
+ *
+ * The instance computes rows [row_begin,row_end) of aggregation, cost sum, both WTAs and the LR check.  The
+ * vertical and diagonal paths cross tile borders, so a tile's sweep in one vertical sense starts from the path
+ * costs of the row just outside the tile -- the neighbouring GPU's last row of that sweep -- which the caller
+ * moves between GPUs (sgm_tile_export_boundary -> RCCL send/recv or a peer copy -> sgm_tile_import_boundary).
+ * Census and the four anomalous diagonal lines are computed on the whole frame by every GPU (the images are
+ * replicated: 2 x W*H bytes; that work is ~1 % of a frame).  Speckle removal and the median are whole-frame
+ * passes over the gathered W*H disparity map (sgm_tile_post). */
+
+static int sweep_mask(const sgm_instance* s, int forward)
+{
+    int m = 0;
+    for (int d = 0; d < s->paths.ndirs; ++d)
+        if (s->paths.dy[d] == (forward ? 1 : -1)) m |= 1 << d;
+    return m;
+}
+
+bool sgm_set_rows(sgm_instance* s, int row_begin, int row_end)
+{
+    if (!s || row_begin < 0 || row_end < 0 || (row_end != 0 && row_begin >= row_end)) return false;
+    s->tile_begin = row_begin;
+    s->tile_end = row_end;
+    s->initialized = false;      /* takes effect at the next sgm_initialize / sgm_reset */
+    return true;
+}
+
+static bool tile_aggregate(sgm_instance* s, int dir_mask, int run_anom)
+{
+    sgmd_paths p = s->paths;
+    p.dir_mask = dir_mask;
+    p.run_anom = run_anom;
+    return sgmd_aggregate(s->device, s->stream, &s->g, &p, s->tile_left, s->d_census_l, s->d_census_r, s->d_lut,
+                          s->d_planes, s->plane_bytes, s->d_extras) == 0;
+}
+
+bool sgm_tile_begin(sgm_instance* s, const uint8_t* d_left, const uint8_t* d_right)
+{
+    if (!s || !s->initialized || !d_left || !d_right) return false;
+    int rc = sgmd_census(s->device, s->stream, &s->g, d_left, d_right, s->d_census_l, s->d_census_r);
+    if (s->need_plane_memset && s->paths.ndirs > 4)
+        rc |= sgmd_memset_async(s->device, s->stream, (char*)s->d_planes + 4 * s->plane_bytes, 0, 4 * s->plane_bytes);
+    if (rc != 0) FAIL("a kernel launch failed");
+    s->tile_left = d_left;
+    int hmask = 0;
+    for (int d = 0; d < s->paths.ndirs; ++d)
+        if (s->paths.dy[d] == 0) hmask |= 1 << d;
+    return tile_aggregate(s, hmask, 1);
+}
+
+size_t sgm_tile_boundary_bytes(const sgm_instance* s)
+{
+    if (!s || !s->initialized) return 0;
+    return (size_t)(s->paths.ndirs > 4 ? 3 : 1) * s->g.W * s->g.Dp;
+}
+
+/* rows of the planes a sweep hands over: `inside` = the tile's last row in walking order, else the row just past
+ * the tile's first row against the walking order (where the neighbour's hand-over lands) */
+static bool boundary_copy(sgm_instance* s, int forward, void* d_buf, bool do_export)
+{
+    if (!s || !s->initialized || !d_buf) return false;
+    const int row = do_export ? (forward ? s->g.row_end - 1 : s->g.row_begin)
+                              : (forward ? s->g.row_begin - 1 : s->g.row_end);
+    if (row < 0 || row >= s->g.H) return false;               /* the tile touches the frame edge: nothing to import */
+    const size_t row_bytes = (size_t)s->g.W * s->g.Dp;
+    const int mask = sweep_mask(s, forward);
+    int n = 0, rc = 0;
+    for (int d = 0; d < s->paths.ndirs; ++d) {
+        if (!((mask >> d) & 1)) continue;
+        char* cell = (char*)s->d_planes + (size_t)d * s->plane_bytes + (size_t)row * row_bytes;
+        char* slot = (char*)d_buf + (size_t)n++ * row_bytes;
+        rc |= do_export ? sgmd_d2d_async(s->device, s->stream, slot, cell, row_bytes)
+                        : sgmd_d2d_async(s->device, s->stream, cell, slot, row_bytes);
+    }
+    return rc == 0;
+}
+
+bool sgm_tile_export_boundary(sgm_instance* s, int forward, void* d_buf) { return boundary_copy(s, forward, d_buf, true); }
+bool sgm_tile_import_boundary(sgm_instance* s, int forward, const void* d_buf)
+{
+    return boundary_copy(s, forward, (void*)d_buf, false);
+}
+
+bool sgm_tile_sweep(sgm_instance* s, int forward)
+{
+    if (!s || !s->initialized || !s->tile_left) return false;
+    return tile_aggregate(s, sweep_mask(s, forward), 0);
+}
+
+bool sgm_tile_finish(sgm_instance* s, float* d_disp_left)
+{
+    if (!s || !s->initialized || !s->tile_left || !d_disp_left) return false;
+    const sgmd_geom* g = &s->g;
+    const SGMOption* o = &s->opt;
+    int rc = sgmd_sum_wta(s->device, s->stream, g, s->paths.ndirs, s->d_planes, s->plane_bytes, s->d_extras,
+                          s->d_row_extras, s->d_row_count, s->row_cap, s->s_is_zero ? 0 : 1, s->d_S,
+                          o->is_check_unique ? 1 : 0, 1 - o->uniqueness_ratio, d_disp_left);
+    s->s_is_zero = false;
+    if (o->is_check_lr) {
+        rc |= sgmd_wta_right(s->device, s->stream, g, s->d_S, o->is_check_unique ? 1 : 0, 1 - o->uniqueness_ratio, s->d_disp_r);
+        rc |= sgmd_lrcheck(s->device, s->stream, g, d_disp_left, s->d_disp_r, o->lrcheck_thres);
+    }
+    s->tile_left = NULL;
+    if (rc != 0) FAIL("a kernel launch failed");
+    return true;
+}
+
+bool sgm_tile_post(sgm_instance* s, float* d_disp_left)
+{
+    if (!s || !s->initialized || !d_disp_left) return false;
+    int rc = 0;
+    if (s->opt.is_remove_speckles)
+        rc |= sgmd_speckle(s->device, s->stream, &s->g, d_disp_left, 1.0f, s->opt.min_speckle_area, s->d_labels, s->d_sizes,
+                           s->d_totals);
+    rc |= sgmd_median(s->device, s->stream, &s->g, d_disp_left, s->d_median_scratch);
+    if (rc != 0) FAIL("a kernel launch failed");
+    return true;
+}
+
 static void collect_timing(sgm_instance* s)
 {
     if (!(s->timing && s->timer)) return;
@@ -461,6 +592,7 @@ bool sgm_match_device(sgm_instance* s, const uint8_t* d_left, const uint8_t* d_r
     if (!s || !s->initialized) return false;                     /* .c:70 */
     if (!d_left || !d_right) return false;                       /* .c:73 */
     if (!d_disp_left) return false;
+    if (s->tile_end != 0) FAIL("the instance is in row-tile mode (sgm_set_rows): use the sgm_tile_* sequence");
     return run_pipeline(s, d_left, d_right, d_disp_left);
 }
 
@@ -477,6 +609,7 @@ bool sgm_match(sgm_instance* s, const uint8_t* img_left, const uint8_t* img_righ
     if (!s || !s->initialized) return false;                     /* .c:70 */
     if (!img_left || !img_right) return false;                   /* .c:73 */
     if (!disp_left) return false;
+    if (s->tile_end != 0) FAIL("the instance is in row-tile mode (sgm_set_rows): use the sgm_tile_* sequence");
     const size_t px = (size_t)s->g.B * s->g.W * s->g.H;           /* batch > 1: B consecutive frames */
     memcpy(s->h_left, img_left, px);
     memcpy(s->h_right, img_right, px);

@@ -162,6 +162,8 @@ struct AggArgs {
     size_t plane_bytes;
     uint8_t* extras;
     int W, H, D, Dp;
+    int row_begin, row_end;     // rows of the frame this launch covers (a row tile of a multi-GPU run; [0,H) normally)
+    int run_anom;               // 1: also run the four anomalous diagonal lines (whole frame)
     int B;                      // frames per launch; frame f uses img/census + f*W*H, planes + f*8*plane_bytes, extras + f*4*H*Dp
     int p1;
     int ndirs;
@@ -390,8 +392,15 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
     const int W = a.W, H = a.H, Dp = a.Dp;
     const bool fwd = (dx == 1 && dy == 0) || (dx == 0 && dy == 1) || (dx == 1 && dy == 1) || (dx == -1 && dy == 1);  // ref :232
     const int s = fwd ? 1 : -1;
-    const int nlines = (KIND == AGG_H) ? H : W;                            // ref :238
-    const int nsteps = ((KIND == AGG_H) ? W : H) - 1;                      // ref :281
+    // Row tile [row_begin, row_end): horizontal lines are the tile's rows; a vertical / diagonal line enters the
+    // tile with the path state of its previous pixel, read from the row just outside the tile in this direction's
+    // plane (written by the neighbouring GPU and copied in), or starts with L = C where the tile touches the frame
+    // edge the direction starts from.  [0,H) = the whole frame = the reference's walk.
+    const int rows = a.row_end - a.row_begin;
+    const int skip = (KIND == AGG_H) ? 0 : (fwd ? a.row_begin : H - a.row_end);    // rows between that edge and the tile
+    const bool import_state = skip > 0;
+    const int nlines = (KIND == AGG_H) ? rows : W;                         // ref :238
+    const int nsteps = (KIND == AGG_H) ? W - 1 : (import_state ? rows : rows - 1);   // ref :281
     if (KIND == AGG_D && W < 2) return;                                    // the only line is the anomalous one
 
     constexpr int LPW = 64 / LPP;                                          // path lines per wave
@@ -422,11 +431,13 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
     int dstep_p = 0, dstep_off = 0;
     if (KIND == AGG_H) {
         x = fwd ? 0 : W - 1;
-        p = (unsigned)(line * W + x);
+        p = (unsigned)((a.row_begin + line) * W + x);
         dstep_p = s; dstep_off = s * Dp;
     } else if (KIND == AGG_V) {
         x = line;
-        p = (unsigned)((fwd ? 0 : (H - 1) * W) + line);
+        // first row of the tile in walking order, or (import) the row before it
+        const int r = fwd ? a.row_begin - (import_state ? 1 : 0) : a.row_end - 1 + (import_state ? 1 : 0);
+        p = (unsigned)(r * W + line);
         dstep_p = s * W; dstep_off = s * W * Dp;
     } else {
         rowpix = (unsigned)(fwd ? 0 : (H - 1) * W);
@@ -468,11 +479,30 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
         g = fr.img[p];
     };
 
-    // ---- first pixel of the line: L = C (ref :266-275) ----
+    // a diagonal line of a row tile: replay the walk from the frame edge up to the pixel before the tile (cheap
+    // register arithmetic; it reproduces the tracker state exactly, early wraps included)
+    if (KIND == AGG_D)
+        for (int i = 0; i + 1 < skip; ++i) advance();
+
     us2 Lp[NP];
     unsigned min_prev;
     int g_prev;
-    {
+    if (import_state) {
+        // ---- state of the previous pixel: its L_r from the plane, its grey value, min over d ----
+        CellVec<DPL> c0;
+        load_cells<DPL>(plane + off, c0);
+        g_prev = fr.img[p];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const unsigned w = c0.w[j >> 1];
+            Lp[j] = as_p(__builtin_amdgcn_perm(w, w, (j & 1) ? 0x0c030c02u : 0x0c010c00u));   // bytes -> u16 pairs
+        }
+        us2 m = Lp[0];
+#pragma unroll
+        for (int j = 1; j < NP; ++j) m = pk_min(m, Lp[j]);
+        min_prev = row_allmin<LPP>(min(as_u(m) & 0xFFFFu, as_u(m) >> 16));
+    } else {
+        // ---- first pixel of the line: L = C (ref :266-275) ----
         CensusVec<DPL> cv;
         unsigned cl;
         fetch(cv, cl, g_prev);
@@ -750,13 +780,13 @@ __global__ __launch_bounds__(256) void sgm_sum_wta_k(const uint8_t* __restrict__
                                                      const sgmd_row_extra* __restrict__ row_extras,
                                                      const int* __restrict__ row_extra_count, int row_cap, int accumulate,
                                                      uint16_t* __restrict__ S, float* __restrict__ disp_l, int W, int H, int D,
-                                                     int Dp, int dmin, int check_unique, float one_minus_ratio)
+                                                     int Dp, int dmin, int check_unique, float one_minus_ratio, int row0)
 {
     const int sub = threadIdx.x & 15;
     const int xr = blockIdx.x * 16 + (threadIdx.x >> 4);
     const bool inside = xr < W;
     const int x = inside ? xr : W - 1;                                  // keep the DPP rows converged; stores are masked
-    const int row = blockIdx.y;
+    const int row = row0 + blockIdx.y;                                  // row0: first row of this GPU's row tile
     const size_t off = ((size_t)row * W + x) * Dp + sub * DPL;
     planes += (size_t)blockIdx.z * 8 * plane_bytes;                     // batch: z = frame
     extras += (size_t)blockIdx.z * 4 * H * Dp;
@@ -844,10 +874,10 @@ __global__ __launch_bounds__(256) void sgm_sum_wta_k(const uint8_t* __restrict__
 
 __global__ __launch_bounds__(WTA_T) void sgm_wta_right_k(const uint16_t* __restrict__ S, float* __restrict__ disp_r, int W,
                                                          int H, int D, int Dp, int dmin, int check_unique,
-                                                         float one_minus_ratio)
+                                                         float one_minus_ratio, int row0)
 {
     __shared__ unsigned short tr[(WTA_T + WTA_DC) * WTA_LD];
-    const int row = blockIdx.y;
+    const int row = row0 + blockIdx.y;
     const int x0 = blockIdx.x * WTA_T;
     const int i = threadIdx.x;
     const int x = x0 + i;
@@ -897,10 +927,10 @@ __global__ __launch_bounds__(WTA_T) void sgm_wta_right_k(const uint16_t* __restr
 // ============================================================================================
 
 __global__ __launch_bounds__(256) void sgm_lrcheck_k(float* __restrict__ dl, const float* __restrict__ dr, int W, int H,
-                                                     float thres)
+                                                     float thres, int row0)
 {
     const int x = blockIdx.x * 256 + threadIdx.x;
-    const int y = blockIdx.y;
+    const int y = row0 + blockIdx.y;
     if (x >= W) return;
     const float inf = __builtin_inff();
     dl += (size_t)blockIdx.z * W * H;                                   // batch: z = frame
@@ -1368,7 +1398,7 @@ static void launch_sum_wta(dim3 grid, hipStream_t st, const void* planes, size_t
     hipLaunchKernelGGL((sgm_sum_wta_k<DPL>), grid, dim3(256), 0, st, (const uint8_t*)planes, plane_bytes, ndirs,
                        (const uint8_t*)extras, (const sgmd_row_extra*)row_extras, (const int*)row_extra_count, row_cap,
                        accumulate, (uint16_t*)S, (float*)disp_l, g->W, g->H, g->D, g->Dp, g->dmin, check_unique,
-                       one_minus_ratio);
+                       one_minus_ratio, g->row_begin);
 }
 
 extern "C" {
@@ -1533,6 +1563,8 @@ int sgmd_aggregate(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* 
     a.extras = (uint8_t*)extras;
     a.W = g->W; a.H = g->H; a.D = g->D; a.Dp = g->Dp;
     a.B = g->B;
+    a.row_begin = g->row_begin; a.row_end = g->row_end;
+    a.run_anom = (paths->ndirs > 4 && paths->run_anom) ? 1 : 0;
     a.p1 = paths->p1;
     a.ndirs = paths->ndirs;
     a.ghost_zero = paths->ghost_zero;
@@ -1540,14 +1572,15 @@ int sgmd_aggregate(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* 
     for (int d = 0; d < 8; ++d) {
         a.dx[d] = paths->dx[d]; a.dy[d] = paths->dy[d]; a.anom_line[d] = paths->anom_line[d];
         a.block_begin[d] = blocks;
-        if (d < paths->ndirs) {
-            const int nlines = (paths->dy[d] == 0) ? g->H : g->W;
+        if (d < paths->ndirs && ((paths->dir_mask >> d) & 1)) {
+            const int nlines = (paths->dy[d] == 0) ? g->row_end - g->row_begin : g->W;
             const int lines_per_wave = (paths->dy[d] == 0 && g->H32) ? 2 : 64 / g->LPP;
             blocks += (nlines + lines_per_wave - 1) / lines_per_wave;
         }
     }
     a.block_begin[8] = blocks;
-    if (paths->ndirs > 4) blocks += 4;                 // one extra wave per diagonal direction: its anomalous line
+    if (a.run_anom) blocks += 4;                       // one extra wave per diagonal direction: its anomalous line
+    if (blocks == 0) return 0;
     blocks *= g->B;                                    // every frame of the batch in the same launch
     const bool pad = (g->D != g->Dp);
     hipStream_t st = (hipStream_t)stream;
@@ -1578,7 +1611,7 @@ int sgmd_sum_wta(int ord, void* stream, const sgmd_geom* g, int ndirs, const voi
                  void* S, int check_unique, float one_minus_ratio, void* disp_l)
 {
     HIP_TRY(hipSetDevice(ord));
-    const dim3 grid((g->W + 15) / 16, g->H, g->B);
+    const dim3 grid((g->W + 15) / 16, g->row_end - g->row_begin, g->B);
     hipStream_t st = (hipStream_t)stream;
 #define SUM_ARGS grid, st, planes, plane_bytes, ndirs, extras, row_extras, row_extra_count, row_cap, accumulate, S, disp_l, g, check_unique, one_minus_ratio
     switch (g->Dp / 16) {                                // 16 lanes per pixel here, whatever the aggregation used
@@ -1601,9 +1634,9 @@ int sgmd_wta_right(int ord, void* stream, const sgmd_geom* g, const void* S, int
                    void* disp_r)
 {
     HIP_TRY(hipSetDevice(ord));
-    dim3 grid((g->W + WTA_T - 1) / WTA_T, g->H, g->B);
+    dim3 grid((g->W + WTA_T - 1) / WTA_T, g->row_end - g->row_begin, g->B);
     hipLaunchKernelGGL(sgm_wta_right_k, grid, dim3(WTA_T), 0, (hipStream_t)stream, (const uint16_t*)S, (float*)disp_r,
-                       g->W, g->H, g->D, g->Dp, g->dmin, check_unique, one_minus_ratio);
+                       g->W, g->H, g->D, g->Dp, g->dmin, check_unique, one_minus_ratio, g->row_begin);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1611,9 +1644,9 @@ int sgmd_wta_right(int ord, void* stream, const sgmd_geom* g, const void* S, int
 int sgmd_lrcheck(int ord, void* stream, const sgmd_geom* g, void* disp_l, const void* disp_r, float thres)
 {
     HIP_TRY(hipSetDevice(ord));
-    dim3 grid((g->W + 255) / 256, g->H, g->B);
+    dim3 grid((g->W + 255) / 256, g->row_end - g->row_begin, g->B);
     hipLaunchKernelGGL(sgm_lrcheck_k, grid, dim3(256), 0, (hipStream_t)stream, (float*)disp_l, (const float*)disp_r,
-                       g->W, g->H, thres);
+                       g->W, g->H, thres, g->row_begin);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -110,6 +110,20 @@ def load_library() -> C.CDLL:
     L.sgm_read_stage.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     L.sgm_read_stage.restype = C.c_size_t
     L.sgm_enable_timing.argtypes = [C.c_void_p, C.c_int]
+    L.sgm_set_rows.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.sgm_set_rows.restype = C.c_bool
+    L.sgm_tile_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.sgm_tile_begin.restype = C.c_bool
+    L.sgm_tile_boundary_bytes.argtypes = [C.c_void_p]
+    L.sgm_tile_boundary_bytes.restype = C.c_size_t
+    for f in (L.sgm_tile_import_boundary, L.sgm_tile_export_boundary):
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        f.restype = C.c_bool
+    L.sgm_tile_sweep.argtypes = [C.c_void_p, C.c_int]
+    L.sgm_tile_sweep.restype = C.c_bool
+    for f in (L.sgm_tile_finish, L.sgm_tile_post):
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        f.restype = C.c_bool
     L.sgm_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
     L.sgm_last_timing.restype = C.c_int
     L.sgm_host_walk_line.argtypes = [C.c_int] * 5 + [C.c_void_p]
@@ -305,6 +319,32 @@ class SGMInstance(_StageReader):
 
     def synchronize(self) -> bool:
         return bool(self.lib.sgm_synchronize(self.handle))
+
+    # ---- row tiles (one frame over several GPUs; include/sgm_mi355x.h "row tiles"); all device pointers ----
+    def set_rows(self, row_begin: int, row_end: int) -> bool:
+        """This instance computes rows [row_begin, row_end) from the next initialize/reset on; (0, 0) = whole frames."""
+        return bool(self.lib.sgm_set_rows(self.handle, row_begin, row_end))
+
+    def tile_begin(self, d_left: int, d_right: int) -> bool:
+        return bool(self.lib.sgm_tile_begin(self.handle, d_left, d_right))
+
+    def tile_boundary_bytes(self) -> int:
+        return int(self.lib.sgm_tile_boundary_bytes(self.handle))
+
+    def tile_import_boundary(self, forward: bool, d_buf: int) -> bool:
+        return bool(self.lib.sgm_tile_import_boundary(self.handle, int(forward), d_buf))
+
+    def tile_sweep(self, forward: bool) -> bool:
+        return bool(self.lib.sgm_tile_sweep(self.handle, int(forward)))
+
+    def tile_export_boundary(self, forward: bool, d_buf: int) -> bool:
+        return bool(self.lib.sgm_tile_export_boundary(self.handle, int(forward), d_buf))
+
+    def tile_finish(self, d_disp: int) -> bool:
+        return bool(self.lib.sgm_tile_finish(self.handle, d_disp))
+
+    def tile_post(self, d_disp: int) -> bool:
+        return bool(self.lib.sgm_tile_post(self.handle, d_disp))
 
     @property
     def stream(self) -> int:

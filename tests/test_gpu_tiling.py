@@ -1,0 +1,149 @@
+"""Row-tile mode (one frame over several GPUs, include/sgm_mi355x.h "row tiles") on ONE MI355X: N instances
+stand in for N GPUs, the hand-over buffers travel exactly as they would between ranks.  The result must be the
+single-GPU result bit for bit -- aggregated cost S on every tile's rows and the final map."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from test_gpu_parity import assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+def _engines(w, h, opt, n, honor4=False):
+    from soc_project_stereo_matching_amd.tiling import DeviceTileEngine, tile_rows
+    out = []
+    for rows in tile_rows(h, n):
+        e = DeviceTileEngine.__new__(DeviceTileEngine)
+        # same as DeviceTileEngine(0, w, h, opt, rows) but with the 4-path switch set before the first reset
+        import torch
+        from soc_project_stereo_matching_amd.sgm import SGMInstance
+        e.torch, e.dev = torch, torch.device("cuda", 0)
+        e.w, e.h, e.rows, e.option = w, h, rows, opt
+        e.inst = SGMInstance(0)
+        e.inst.set_honor_num_paths(honor4)
+        assert e.inst.set_rows(*rows)
+        assert e.inst.reset(w, h, opt)
+        e.disp = torch.empty((h, w), dtype=torch.float32, device=e.dev)
+        e.nbytes = e.inst.tile_boundary_bytes()
+        out.append(e)
+    return out
+
+
+@pytest.mark.parametrize("case", [
+    # W, H, dmin, dmax, tiles, option overrides
+    (130, 47, 2, 50, 2, {}),                       # padded disparity range, odd sizes
+    (130, 47, 2, 50, 5, {}),
+    (64, 7, 0, 16, 7, {}),                         # one row per tile
+    (37, 61, 0, 8, 3, {}),                         # W < H: diagonals wrap several times, planes pre-cleared
+    (257, 64, 0, 100, 4, {"is_check_unique": False}),
+    (320, 96, 0, 64, 3, {"is_check_lr": False, "is_remove_speckles": False}),
+    (450, 375, 0, 64, 8, {}),                      # the reference's own capacity, 8 tiles as on an 8-GPU node
+    (200, 40, 0, 256, 2, {}),
+], ids=lambda c: f"{c[0]}x{c[1]}_d{c[2]}-{c[3]}_n{c[4]}")
+def test_tiles_reproduce_the_single_gpu_result(oracle, case):
+    import torch
+    from oracle.pyoracle import default_option
+    from soc_project_stereo_matching_amd.tiling import match_tiled_in_process
+    w, h, dmin, dmax, n, over = case
+    opt = default_option(dmax, dmin, **over)
+    left, right = oracle.synth_pair(w, h, dmax - dmin, 0x71E0 + w + n)
+    want = oracle.run(left, right, opt)
+    engines = _engines(w, h, opt, n)
+    try:
+        dl, dr = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+        got = match_tiled_in_process(engines, dl, dr).cpu().numpy()
+        for e in engines:                                          # S on the rows each tile owns
+            r0, r1 = e.rows
+            assert_same(e.inst.read_stage("aggr")[r0:r1], want["aggr"][r0:r1], f"S rows {r0}:{r1}")
+        assert_same(got, want["final"], "final")
+        # a second frame through the same engines (per-frame Reset inside begin())
+        left2, right2 = oracle.synth_pair(w, h, dmax - dmin, 0x71E1 + w + n)
+        got2 = match_tiled_in_process(engines, torch.from_numpy(left2).cuda(), torch.from_numpy(right2).cuda())
+        assert_same(got2.cpu().numpy(), oracle.run(left2, right2, opt)["final"], "second frame")
+    finally:
+        for e in engines:
+            e.close()
+
+
+def test_tiles_four_path_mode(oracle):
+    import torch
+    from oracle.pyoracle import default_option
+    from soc_project_stereo_matching_amd.tiling import match_tiled_in_process
+    w, h, d = 160, 50, 32
+    opt = default_option(d, num_paths=4)
+    left, right = oracle.synth_pair(w, h, d, 0x4A7)
+    oracle.set_honor_num_paths(True)
+    engines = _engines(w, h, opt, 3, honor4=True)
+    try:
+        want = oracle.run(left, right, opt)["final"]
+        assert engines[0].inst.tile_boundary_bytes() == w * 32      # one direction per sweep, Dp = 32
+        got = match_tiled_in_process(engines, torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda())
+        assert_same(got.cpu().numpy(), want, "4-path tiled")
+    finally:
+        oracle.set_honor_num_paths(False)
+        for e in engines:
+            e.close()
+
+
+def test_tile_mode_guards():
+    import soc_project_stereo_matching_amd as S
+    i = S.SGMInstance(0)
+    try:
+        opt = S.default_option(16)
+        assert i.set_rows(10, 20)
+        assert not i.reset(64, 15, opt)                            # tile beyond the frame
+        assert i.reset(64, 32, opt)
+        assert i.match(np.zeros((32, 64), np.uint8), np.zeros((32, 64), np.uint8)) is None   # whole-frame call refused
+        assert not i.tile_sweep(True)                              # no tile_begin yet
+        assert i.set_rows(0, 0) and i.reset(64, 32, opt)
+        assert i.match(np.zeros((32, 64), np.uint8), np.zeros((32, 64), np.uint8)) is not None
+        assert not i.set_rows(5, 3)
+    finally:
+        i.close()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_main(rank, world, port, w, h, d, seed, out_path):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import soc_project_stereo_matching_amd as S
+    from soc_project_stereo_matching_amd.tiling import DeviceTileEngine, make_links, match_tiled, tile_rows
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    links = make_links(dist)
+    opt = S.default_option(d)
+    eng = DeviceTileEngine(0, w, h, opt, tile_rows(h, world)[rank])      # every rank on the box's one GPU
+    for k in range(2):
+        left, right = S.synth_pair(w, h, d, seed + k)
+        full = match_tiled(eng, rank, world, torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda(), h,
+                           dist=dist, links=links)
+        if rank == world - 1:
+            np.save(out_path + f".{k}.npy", full.cpu().numpy())
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+
+
+def test_three_ranks_over_a_process_group(tmp_path, oracle):
+    """The distributed wrapper end to end: three processes (sharing this box's one GPU), hand-overs and the row
+    gather over a gloo group (host-staged); on a multi-GPU node the same code runs with backend nccl (= RCCL)."""
+    import torch.multiprocessing as mp
+    from oracle.pyoracle import default_option
+    w, h, d, seed, world = 300, 70, 48, 0xBEEF, 3
+    out = str(tmp_path / "tiled")
+    mp.spawn(_rank_main, args=(world, _free_port(), w, h, d, seed, out), nprocs=world, join=True)
+    for k in range(2):
+        l, r = oracle.synth_pair(w, h, d, seed + k)
+        assert_same(np.load(out + f".{k}.npy"), oracle.run(l, r, default_option(d))["final"], f"frame {k}")
