@@ -160,6 +160,9 @@ void   SGM_KeepStages(int enable);
  * Returns the number of entries written (<= max_entries). */
 void   sgm_enable_timing(sgm_instance* s, int enable);
 int    sgm_last_timing(sgm_instance* s, const char** names, float* ms, int max_entries);
+/* Mean and minimum per-kernel time over every match since timing was (re-)enabled and collected by
+ * sgm_synchronize (up to 64 matches between two synchronizes are kept); *matches = how many. */
+int    sgm_mean_timing(sgm_instance* s, const char** names, float* mean_ms, float* min_ms, int max_entries, long* matches);
 
 /* Seeded synthetic stereo pair of SURVEY.md 8(d) (host buffers of width*height bytes each). */
 void   SGM_SynthPair(int width, int height, int disparity_range, uint32_t seed, uint8_t* left, uint8_t* right);

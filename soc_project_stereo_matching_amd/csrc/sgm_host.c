@@ -21,6 +21,7 @@
 #define SGM_VERSION_STRING "sgm_mi355x 0.1 (gfx950, hand-written HIP)"
 #define CENSUS_FRONT_SLACK ((size_t)(65535 + SGM_MAX_DISPARITY_RANGE + 8 + 63) / 64 * 64 * 4)   /* >= sgmd_census_slack() for any options */
 
+#define TIMING_RING 64
 enum { T_CENSUS, T_COST, T_AGGREGATE, T_SUM, T_WTA, T_LRCHECK, T_SPECKLE, T_MEDIAN, T_COUNT };
 static const char* const k_stage_names[T_COUNT] = {"census", "cost", "aggregate", "sum", "wta", "lrcheck", "speckle", "median"};
 
@@ -49,6 +50,10 @@ struct sgm_instance {
     int row_cap;
     float last_ms[T_COUNT];
     bool have_ms;
+    /* timing history: TIMING_RING event sets, one per match since the last collection */
+    int ring_next, ring_pending;          /* next set to record into; sets recorded and not yet read */
+    double sum_ms[T_COUNT], min_ms[T_COUNT];
+    long n_timed;
 
     /* device buffers (capacity tracked so a Reset with the same shape allocates nothing) */
     size_t cap_px, cap_cells, cap_extras, cap_median;
@@ -203,8 +208,26 @@ void* sgm_stream(sgm_instance* s) { return s ? s->stream : NULL; }
 void sgm_enable_timing(sgm_instance* s, int enable)
 {
     if (!s) return;
-    if (enable && !s->timer && sgmd_timer_create(s->device, &s->timer, T_COUNT + 1) != 0) return;
+    if (enable && !s->timer && sgmd_timer_create(s->device, &s->timer, TIMING_RING * (T_COUNT + 1)) != 0) return;
     s->timing = enable;
+    /* (re-)enabling starts a new statistics window: drop what was recorded before */
+    sgmd_stream_sync(s->device, s->stream);
+    s->ring_next = s->ring_pending = 0;
+    s->n_timed = 0;
+    for (int i = 0; i < T_COUNT; ++i) { s->sum_ms[i] = 0; s->min_ms[i] = 1e30; }
+}
+
+int sgm_mean_timing(sgm_instance* s, const char** names, float* mean_ms, float* min_ms, int max_entries, long* matches)
+{
+    if (matches) *matches = s ? s->n_timed : 0;
+    if (!s || s->n_timed == 0) return 0;
+    int n = 0;
+    for (int i = 0; i < T_COUNT && n < max_entries; ++i, ++n) {
+        if (names) names[n] = k_stage_names[i];
+        if (mean_ms) mean_ms[n] = (float)(s->sum_ms[i] / (double)s->n_timed);
+        if (min_ms) min_ms[n] = (float)s->min_ms[i];
+    }
+    return n;
 }
 
 int sgm_last_timing(sgm_instance* s, const char** names, float* ms, int max_entries)
@@ -412,7 +435,7 @@ bool sgm_reset(sgm_instance* s, uint16_t width, uint16_t height, const SGMOption
 
 static void mark(sgm_instance* s, int idx)
 {
-    if (s->timing && s->timer) sgmd_timer_mark(s->device, s->timer, s->stream, idx);
+    if (s->timing && s->timer) sgmd_timer_mark(s->device, s->timer, s->stream, s->ring_next * (T_COUNT + 1) + idx);
 }
 
 /* The body of SGM_Match (SemiGlobalMatching.c:80-122) on device buffers. */
@@ -456,6 +479,10 @@ static bool run_pipeline(sgm_instance* s, const void* d_left, const void* d_righ
     mark(s, 7);
     rc |= sgmd_median(dev, st, g, d_out, s->d_median_scratch);                                                       /* .c:120 */
     mark(s, 8);
+    if (s->timing && s->timer) {
+        s->ring_next = (s->ring_next + 1) % TIMING_RING;
+        if (s->ring_pending < TIMING_RING) ++s->ring_pending;      /* older sets are overwritten */
+    }
     if (rc != 0) FAIL("a kernel launch failed");
     return true;
 }
@@ -582,9 +609,23 @@ bool sgm_tile_post(sgm_instance* s, float* d_disp_left)
 static void collect_timing(sgm_instance* s)
 {
     if (!(s->timing && s->timer)) return;
-    for (int i = 0; i < T_COUNT; ++i)
-        if (sgmd_timer_elapsed(s->device, s->timer, i, i + 1, &s->last_ms[i]) != 0) return;
-    s->have_ms = true;
+    /* every match recorded since the last collection (the stream is idle here), oldest first */
+    while (s->ring_pending > 0) {
+        const int set = ((s->ring_next - s->ring_pending) % TIMING_RING + TIMING_RING) % TIMING_RING;
+        const int base = set * (T_COUNT + 1);
+        --s->ring_pending;
+        float ms[T_COUNT];
+        bool ok = true;
+        for (int i = 0; i < T_COUNT && ok; ++i) ok = sgmd_timer_elapsed(s->device, s->timer, base + i, base + i + 1, &ms[i]) == 0;
+        if (!ok) continue;
+        for (int i = 0; i < T_COUNT; ++i) {
+            s->last_ms[i] = ms[i];
+            s->sum_ms[i] += ms[i];
+            if (ms[i] < s->min_ms[i]) s->min_ms[i] = ms[i];
+        }
+        ++s->n_timed;
+        s->have_ms = true;
+    }
 }
 
 bool sgm_match_device(sgm_instance* s, const uint8_t* d_left, const uint8_t* d_right, float* d_disp_left)

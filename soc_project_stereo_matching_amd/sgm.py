@@ -126,6 +126,9 @@ def load_library() -> C.CDLL:
         f.restype = C.c_bool
     L.sgm_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int]
     L.sgm_last_timing.restype = C.c_int
+    L.sgm_mean_timing.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
+                                  C.POINTER(C.c_long)]
+    L.sgm_mean_timing.restype = C.c_int
     L.sgm_host_walk_line.argtypes = [C.c_int] * 5 + [C.c_void_p]
     L.sgm_host_walk_line.restype = C.c_int
     L.sgm_host_anomalous_line.argtypes = [C.c_int, C.c_int]
@@ -290,6 +293,16 @@ class SGMInstance(_StageReader):
         ms = (C.c_float * 16)()
         n = self.lib.sgm_last_timing(self.handle, names, ms, 16)
         return {names[i].decode(): float(ms[i]) for i in range(n)}
+
+    def mean_timing(self):
+        """({stage: mean ms}, {stage: min ms}, matches) over every match since enable_timing()."""
+        names = (C.c_char_p * 16)()
+        mean = (C.c_float * 16)()
+        mn = (C.c_float * 16)()
+        cnt = C.c_long(0)
+        n = self.lib.sgm_mean_timing(self.handle, names, mean, mn, 16, C.byref(cnt))
+        return ({names[i].decode(): float(mean[i]) for i in range(n)},
+                {names[i].decode(): float(mn[i]) for i in range(n)}, int(cnt.value))
 
     def initialize(self, width, height, option) -> bool:
         ok = bool(self.lib.sgm_initialize(self.handle, width, height, C.byref(option)))
