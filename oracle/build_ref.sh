@@ -19,6 +19,10 @@ SRC="$REF/SemiGlobalMatching.c"
 OUT="$HERE/_ref"
 mkdir -p "$OUT"
 
+# the reference's buffers are static arrays: past 2 GB of .bss the default code model cannot address them
+MODEL=""
+[ $((W * H * D)) -gt 300000000 ] && MODEL="-mcmodel=medium"
+
 GUARD_RE='^[[:space:]]*gray = \*img_pos;'
 COUNTER_RE='for (uint8_t f = 0; f < sgm\.disp_range; f++)'
 [ "$(grep -c "$GUARD_RE" "$SRC")" = 1 ]   || { echo "guard anchor not unique"; exit 4; }
@@ -29,6 +33,6 @@ COUNTER_RE='for (uint8_t f = 0; f < sgm\.disp_range; f++)'
   sed -e "/$GUARD_RE/i if (img_pos < img_data || img_pos >= img_data + (size_t)sgm.width * sgm.height) { ref_oob_dropped++; break; }" \
       -e "s/$COUNTER_RE/for (uint16_t f = 0; f < sgm.disp_range; f++)/" "$SRC"
   cat "$HERE/ref_harness_tail.c"
-} | gcc -O2 -w -x c - -I"$REF" -DREF_W="$W" -DREF_H="$H" -DREF_D="$D" \
+} | gcc -O2 -w $MODEL -x c - -I"$REF" -DREF_W="$W" -DREF_H="$H" -DREF_D="$D" \
         -shared -fPIC -o "$OUT/libsgm_ref_${W}x${H}x${D}.so" -lm
 echo "built $OUT/libsgm_ref_${W}x${H}x${D}.so"

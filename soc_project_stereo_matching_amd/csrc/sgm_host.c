@@ -43,6 +43,10 @@ struct sgm_instance {
 
     bool initialized;
     bool s_is_zero;              /* aggregated-cost volume logically zero (set by Initialize/Reset, Q14) */
+    int fused_wta;               /* Dp <= 128: cost sum and both WTA passes in one kernel, S not written */
+    bool s_pending;              /* the planes hold a frame whose sum has not been put into d_S (fused kernel, S not
+                                    stored): done lazily when somebody needs S -- a Match without Reset, a stage read */
+    bool s_pending_accumulate;   /* ... and that sum adds to d_S (true) or replaces it */
     SGMOption opt;
     sgmd_geom g;
     sgmd_paths paths;
@@ -421,6 +425,11 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
     }
 
     s->s_is_zero = true;                                         /* .c:57: memset of cost_aggr, done lazily */
+    s->s_pending = false;
+    {
+        const char* e = getenv("SGM_FUSED_WTA");
+        s->fused_wta = sgmd_sum_wta_lr_supported(&s->g) && !((e && *e) && atoi(e) == 0);
+    }
     s->have_ms = false;
     s->initialized = true;
     return true;
@@ -438,6 +447,43 @@ static void mark(sgm_instance* s, int idx)
     if (s->timing && s->timer) sgmd_timer_mark(s->device, s->timer, s->stream, s->ring_next * (T_COUNT + 1) + idx);
 }
 
+/* d_S <- [d_S +] sum of the planes of the last frame, if the fused kernel skipped that store */
+static int materialize_S(sgm_instance* s)
+{
+    if (!s->s_pending) return 0;
+    s->s_pending = false;
+    /* the left-view WTA this kernel also produces goes to a dead scratch map (speckle labels) */
+    return sgmd_sum_wta(s->device, s->stream, &s->g, s->paths.ndirs, s->d_planes, s->plane_bytes, s->d_extras, s->d_row_extras,
+                        s->d_row_count, s->row_cap, s->s_pending_accumulate ? 1 : 0, s->d_S, 0, 0.0f, s->d_labels);
+}
+
+/* .c:94 (sum over the directions), .c:99 and .c:105 (both ComputeDisparity calls) */
+static int sum_and_wta(sgm_instance* s, void* d_out, bool with_marks)
+{
+    const SGMOption* o = &s->opt;
+    const int accumulate = s->s_is_zero ? 0 : 1;                 /* Q14 */
+    const int uniq = o->is_check_unique ? 1 : 0;
+    const float keep = 1 - o->uniqueness_ratio;
+    int rc;
+    if (s->fused_wta) {
+        const int store = s->keep_stages ? 1 : 0;
+        rc = sgmd_sum_wta_lr(s->device, s->stream, &s->g, s->paths.ndirs, s->d_planes, s->plane_bytes, s->d_extras,
+                             s->d_row_extras, s->d_row_count, s->row_cap, accumulate, store, o->is_check_lr ? 1 : 0, s->d_S,
+                             uniq, keep, d_out, s->d_disp_r);
+        s->s_pending = !store;
+        s->s_pending_accumulate = accumulate != 0;
+        if (with_marks) mark(s, 4);
+    } else {
+        rc = sgmd_sum_wta(s->device, s->stream, &s->g, s->paths.ndirs, s->d_planes, s->plane_bytes, s->d_extras,
+                          s->d_row_extras, s->d_row_count, s->row_cap, accumulate, s->d_S, uniq, keep, d_out);
+        if (with_marks) mark(s, 4);
+        if (o->is_check_lr) rc |= sgmd_wta_right(s->device, s->stream, &s->g, s->d_S, uniq, keep, s->d_disp_r);
+        s->s_pending = false;
+    }
+    s->s_is_zero = false;
+    return rc;
+}
+
 /* The body of SGM_Match (SemiGlobalMatching.c:80-122) on device buffers. */
 static bool run_pipeline(sgm_instance* s, const void* d_left, const void* d_right, void* d_out)
 {
@@ -448,6 +494,7 @@ static bool run_pipeline(sgm_instance* s, const void* d_left, const void* d_righ
     const size_t px_bytes = (size_t)g->B * g->W * g->H * sizeof(float);
     int rc = 0;
 
+    if (!s->s_is_zero) rc |= materialize_S(s);               /* Match without Reset: S of the previous frame is needed now */
     mark(s, 0);
     rc |= sgmd_census(dev, st, g, d_left, d_right, s->d_census_l, s->d_census_r);              /* .c:82-83 */
     mark(s, 1);
@@ -461,13 +508,7 @@ static bool run_pipeline(sgm_instance* s, const void* d_left, const void* d_righ
     rc |= sgmd_aggregate(dev, st, g, &s->paths, d_left, s->d_census_l, s->d_census_r, s->d_lut, s->d_planes, s->plane_bytes,
                          s->d_extras);                                                          /* .c:94 */
     mark(s, 3);
-    rc |= sgmd_sum_wta(dev, st, g, s->paths.ndirs, s->d_planes, s->plane_bytes, s->d_extras, s->d_row_extras,
-                       s->d_row_count, s->row_cap, s->s_is_zero ? 0 : 1, s->d_S, o->is_check_unique ? 1 : 0,
-                       1 - o->uniqueness_ratio, d_out);                                         /* .c:94 sum, .c:99 */
-    s->s_is_zero = false;                                                                       /* Q14 */
-    mark(s, 4);
-    if (o->is_check_lr)
-        rc |= sgmd_wta_right(dev, st, g, s->d_S, o->is_check_unique ? 1 : 0, 1 - o->uniqueness_ratio, s->d_disp_r);  /* .c:105 */
+    rc |= sum_and_wta(s, d_out, true);                                                          /* .c:94 sum, .c:99, .c:105 */
     if (s->keep_stages) rc |= sgmd_d2d_async(dev, st, s->d_snap_wta, d_out, px_bytes);
     mark(s, 5);
     if (o->is_check_lr) rc |= sgmd_lrcheck(dev, st, g, d_out, s->d_disp_r, o->lrcheck_thres);   /* .c:109 */
@@ -526,7 +567,8 @@ static bool tile_aggregate(sgm_instance* s, int dir_mask, int run_anom)
 bool sgm_tile_begin(sgm_instance* s, const uint8_t* d_left, const uint8_t* d_right)
 {
     if (!s || !s->initialized || !d_left || !d_right) return false;
-    int rc = sgmd_census(s->device, s->stream, &s->g, d_left, d_right, s->d_census_l, s->d_census_r);
+    int rc = s->s_is_zero ? 0 : materialize_S(s);
+    rc |= sgmd_census(s->device, s->stream, &s->g, d_left, d_right, s->d_census_l, s->d_census_r);
     if (s->need_plane_memset && s->paths.ndirs > 4)
         rc |= sgmd_memset_async(s->device, s->stream, (char*)s->d_planes + 4 * s->plane_bytes, 0, 4 * s->plane_bytes);
     if (rc != 0) FAIL("a kernel launch failed");
@@ -581,14 +623,8 @@ bool sgm_tile_finish(sgm_instance* s, float* d_disp_left)
     if (!s || !s->initialized || !s->tile_left || !d_disp_left) return false;
     const sgmd_geom* g = &s->g;
     const SGMOption* o = &s->opt;
-    int rc = sgmd_sum_wta(s->device, s->stream, g, s->paths.ndirs, s->d_planes, s->plane_bytes, s->d_extras,
-                          s->d_row_extras, s->d_row_count, s->row_cap, s->s_is_zero ? 0 : 1, s->d_S,
-                          o->is_check_unique ? 1 : 0, 1 - o->uniqueness_ratio, d_disp_left);
-    s->s_is_zero = false;
-    if (o->is_check_lr) {
-        rc |= sgmd_wta_right(s->device, s->stream, g, s->d_S, o->is_check_unique ? 1 : 0, 1 - o->uniqueness_ratio, s->d_disp_r);
-        rc |= sgmd_lrcheck(s->device, s->stream, g, d_disp_left, s->d_disp_r, o->lrcheck_thres);
-    }
+    int rc = sum_and_wta(s, d_disp_left, false);
+    if (o->is_check_lr) rc |= sgmd_lrcheck(s->device, s->stream, g, d_disp_left, s->d_disp_r, o->lrcheck_thres);
     s->tile_left = NULL;
     if (rc != 0) FAIL("a kernel launch failed");
     return true;
@@ -701,6 +737,7 @@ size_t sgm_read_stage(sgm_instance* s, int which, void* host_out, size_t capacit
     }
     if (!src) return 0;
     if ((which == 2 || which == 4 || which == 6 || which == 7) && !s->keep_stages) return 0;
+    if (which == 3 && materialize_S(s) != 0) return 0;
     const size_t need = volume ? px * s->g.D * elem : px * elem;
     if (capacity < need) return 0;
     if (sgmd_stream_sync(s->device, s->stream) != 0) return 0;

@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <math.h>
 #include <string.h>
+#include <type_traits>
 
 #include "sgm_device.h"
 
@@ -859,6 +860,206 @@ __global__ __launch_bounds__(256) void sgm_sum_wta_k(const uint8_t* __restrict__
 }
 
 // ============================================================================================
+// Fused cost sum + BOTH winner-take-all passes (Dp <= 128): one workgroup walks one image row, 16 columns per
+// iteration (16 lanes per pixel as in sgm_sum_wta_k).  The S vectors of the last Dp+32 columns stay in an LDS
+// ring, so the right view -- cost of right pixel xr at disparity d is S[y][xr+d][d-dmin] (ref :397-408), a
+// diagonal through Dp consecutive columns -- is evaluated from LDS as soon as its last column has been summed,
+// with the same 16-lane key-min reduction as the left view.  S itself is then needed by nobody: it is written
+// only on request (stage read-back; the host materialises it lazily for a Match without Reset, Q14).  Per
+// frame that removes the S write (119 MB at KITTI size) and the S read of sgm_wta_right_k (143 MB) of 1.37 GB.
+//   ring: u16 [R][LD], R = Dp + 32 columns, LD = Dp + 2 (odd dword stride); entries of columns >= W and of
+//   padding disparities hold 65535 = the reference's "off the image" cost (ref :407).
+// ============================================================================================
+template <int DPL, int STAGE>
+static __device__ __forceinline__ void sumlr_prefetch(CellVec<DPL> (&pre)[2][8], const uint8_t* planes, size_t plane_bytes,
+                                                      int ndirs, size_t off, bool live)
+{
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+#pragma unroll
+        for (int k = 0; k < (DPL + 3) / 4; ++k) pre[STAGE][d].w[k] = 0;
+        if (live && d < ndirs) load_cells_nt<DPL>(planes + (size_t)d * plane_bytes + off, pre[STAGE][d]);
+    }
+}
+
+template <int DPL>
+__global__ __launch_bounds__(256) void sgm_sum_wta_lr_k(const uint8_t* __restrict__ planes, size_t plane_bytes, int ndirs,
+                                                        const uint8_t* __restrict__ extras,
+                                                        const sgmd_row_extra* __restrict__ row_extras,
+                                                        const int* __restrict__ row_extra_count, int row_cap,
+                                                        int accumulate, int store_S, int do_right,
+                                                        uint16_t* __restrict__ S, float* __restrict__ disp_l,
+                                                        float* __restrict__ disp_r, int W, int H, int D, int dmin,
+                                                        int check_unique, float one_minus_ratio, int row0)
+{
+    constexpr int Dp = 16 * DPL;
+    constexpr int LD = Dp + 2;
+    constexpr int R = Dp + 32;
+    __shared__ unsigned short ring[R * LD];
+
+    const int sub = threadIdx.x & 15;
+    const int px = threadIdx.x >> 4;
+    const int row = row0 + blockIdx.x;
+    planes += (size_t)blockIdx.y * 8 * plane_bytes;                     // batch: y = frame
+    extras += (size_t)blockIdx.y * 4 * H * Dp;
+    S += (size_t)blockIdx.y * W * H * Dp;
+    disp_l += (size_t)blockIdx.y * W * H;
+    disp_r += (size_t)blockIdx.y * W * H;
+    const size_t row_cells = (size_t)row * W * Dp;
+    const int n_extra = (ndirs > 4) ? row_extra_count[row] : 0;
+
+    // iterations: the last right pixel (W-1) completes with column W-1 + dmin + D-1; without the right view the
+    // row ends with its last column
+    const int last_col = do_right ? W - 1 + dmin + D - 1 : W - 1;
+    const int n_iter = last_col / 16 + 1;
+
+    CellVec<DPL> pre[2][8];
+    sumlr_prefetch<DPL, 0>(pre, planes, plane_bytes, ndirs, row_cells + (size_t)px * Dp + sub * DPL, px < W);
+    sumlr_prefetch<DPL, 1>(pre, planes, plane_bytes, ndirs, row_cells + (size_t)(16 + px) * Dp + sub * DPL, 16 + px < W);
+
+    int slot = px;                                                       // ring slot of this thread's column: x mod R
+    auto body = [&](int it, auto stage_tag) {
+        constexpr int STAGE = decltype(stage_tag)::value;
+        const int x = it * 16 + px;
+        const bool inside = x < W;
+        const size_t off = row_cells + (size_t)x * Dp + sub * DPL;
+        unsigned acc[DPL];
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) acc[i] = 0;
+        if (it * 16 < W) {                                               // wave-uniform: a column of the image
+            if (accumulate && inside) {                                  // Q14: S was not reset since the last frame
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) acc[i] = S[off + i];
+            }
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) acc[i] += (pre[STAGE][d].w[i >> 2] >> (8 * (i & 3))) & 0xFF;
+            }
+            // refill this stage with the columns of iteration it + 2
+            {
+                const int xn = x + 32;
+                sumlr_prefetch<DPL, STAGE>(pre, planes, plane_bytes, ndirs, row_cells + (size_t)xn * Dp + sub * DPL, xn < W);
+            }
+            for (int j = 0; j < n_extra; ++j) {
+                const sgmd_row_extra e = row_extras[row * row_cap + j];
+                if (inside && (e.col_slot & 0xFFFF) == x) {
+                    CellVec<DPL> v;
+                    load_cells<DPL>(extras + ((size_t)(e.col_slot >> 16) * H + e.step) * Dp + sub * DPL, v);
+#pragma unroll
+                    for (int i = 0; i < DPL; ++i) acc[i] += (v.w[i >> 2] >> (8 * (i & 3))) & 0xFF;
+                }
+            }
+            if (store_S && inside) {
+                unsigned short* dst = S + off;
+#pragma unroll
+                for (int i = 0; i < DPL; i += 2)
+                    *reinterpret_cast<unsigned*>(dst + i) = (acc[i] & 0xFFFFu) | (acc[i + 1] << 16);
+            }
+        }
+        // ---- this column's S vector into the ring (65535 outside the image / the disparity range) ----
+        if (do_right) {
+            unsigned* dst = reinterpret_cast<unsigned*>(&ring[slot * LD + sub * DPL]);
+#pragma unroll
+            for (int i = 0; i < DPL; i += 2) {
+                const int idx = sub * DPL + i;
+                const unsigned lo = (inside && idx < D) ? (acc[i] & 0xFFFFu) : 0xFFFFu;
+                const unsigned hi = (inside && idx + 1 < D) ? (acc[i + 1] & 0xFFFFu) : 0xFFFFu;
+                dst[i >> 1] = lo | (hi << 16);
+            }
+        }
+        // ---- left-view WTA over the 16 lanes of the pixel (as in sgm_sum_wta_k) ----
+        if (it * 16 < W) {
+            unsigned key[DPL];
+            unsigned kmin = 0xFFFFFFFFu;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) {
+                const int idx = sub * DPL + i;
+                key[i] = (idx < D) ? (((acc[i] & 0xFFFFu) << 16) | (unsigned)idx) : 0xFFFFFFFFu;
+                kmin = min(kmin, key[i]);
+            }
+            const unsigned kbest = row_allmin<16>(kmin);
+            unsigned k2 = 0xFFFFFFFFu;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) k2 = min(k2, key[i] == kbest ? 0xFFFFFFFFu : key[i]);
+            const unsigned ksecond = row_allmin<16>(k2);
+            const int dbest = (int)(kbest & 0xFFFFu);
+            unsigned nb = 0;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) {
+                const int idx = sub * DPL + i;
+                if (idx == dbest - 1) nb |= acc[i] & 0xFFFFu;
+                if (idx == dbest + 1) nb |= acc[i] << 16;
+            }
+            nb = row_allor(nb);
+            if (inside && sub == 0) {
+                WtaState st;
+                st.m1 = kbest >> 16;
+                st.m2 = ksecond >> 16;
+                st.d1 = (kbest == 0xFFFFFFFFu) ? -1 : dbest;
+                st.c1 = nb & 0xFFFFu;
+                st.c2 = nb >> 16;
+                st.pv = 0; st.want_next = false;
+                disp_l[(size_t)row * W + x] = wta_finish(st, D, dmin, check_unique, one_minus_ratio);
+            }
+        }
+        if (do_right) {
+            __syncthreads();                                             // the 16 new columns are in the ring
+            // ---- right-view WTA of the pixel whose last column (disparity D-1) is this thread's column ----
+            const int xr = x - dmin - (D - 1);
+            // ring slot of column xr + dmin = x - (D-1)
+            int base = slot + R - (D - 1);
+            if (base >= R) base -= R;
+            unsigned key[DPL], val[DPL];
+            unsigned kmin = 0xFFFFFFFFu;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) {
+                const int k = sub * DPL + i;
+                int sl = base + k;
+                if (sl >= R) sl -= R;
+                val[i] = ring[sl * LD + k];                              // padding disparities hold 65535
+            }
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) {
+                const int k = sub * DPL + i;
+                key[i] = (k < D) ? ((val[i] << 16) | (unsigned)k) : 0xFFFFFFFFu;
+                kmin = min(kmin, key[i]);
+            }
+            const unsigned kbest = row_allmin<16>(kmin);
+            unsigned k2 = 0xFFFFFFFFu;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) k2 = min(k2, key[i] == kbest ? 0xFFFFFFFFu : key[i]);
+            const unsigned ksecond = row_allmin<16>(k2);
+            const int dbest = (int)(kbest & 0xFFFFu);
+            unsigned nb = 0;                                             // S[best-1] | S[best+1] << 16; a best at either end of
+#pragma unroll                                                           // the range is invalid anyway (ref :428)
+            for (int i = 0; i < DPL; ++i) {
+                const int k = sub * DPL + i;
+                if (k == dbest - 1) nb |= val[i];
+                if (k == dbest + 1) nb |= val[i] << 16;
+            }
+            nb = row_allor(nb);
+            if (xr >= 0 && xr < W && sub == 0) {
+                WtaState st;
+                st.m1 = kbest >> 16;
+                st.m2 = ksecond >> 16;
+                st.d1 = ((kbest >> 16) == 0xFFFFu) ? -1 : dbest;         // nothing beat 65535 (ref :381, strict '>')
+                st.c1 = nb & 0xFFFFu;
+                st.c2 = nb >> 16;
+                st.pv = 0; st.want_next = false;
+                disp_r[(size_t)row * W + xr] = wta_finish(st, D, dmin, check_unique, one_minus_ratio);
+            }
+        }
+        slot += 16;
+        if (slot >= R) slot -= R;
+    };
+    for (int it = 0; it < n_iter; it += 2) {
+        body(it, std::integral_constant<int, 0>{});
+        if (it + 1 < n_iter) body(it + 1, std::integral_constant<int, 1>{});
+    }
+}
+
+// ============================================================================================
 // right-view winner-take-all  (ref :374-443 with inverse == 1): cost of right pixel x at disparity d is
 // S[y][x+d][d], 65535 where x+d is off the image (ref :397-408).
 //
@@ -1391,6 +1592,18 @@ static void launch_aggregate(const AggArgs& a, int blocks, bool pad, bool h32, h
 }
 
 template <int DPL>
+static void launch_sum_wta_lr(dim3 grid, hipStream_t st, const void* planes, size_t plane_bytes, int ndirs, const void* extras,
+                              const void* row_extras, const void* row_extra_count, int row_cap, int accumulate, int store_S,
+                              int do_right, void* S, void* disp_l, void* disp_r, const sgmd_geom* g, int check_unique,
+                              float one_minus_ratio)
+{
+    hipLaunchKernelGGL((sgm_sum_wta_lr_k<DPL>), grid, dim3(256), 0, st, (const uint8_t*)planes, plane_bytes, ndirs,
+                       (const uint8_t*)extras, (const sgmd_row_extra*)row_extras, (const int*)row_extra_count, row_cap,
+                       accumulate, store_S, do_right, (uint16_t*)S, (float*)disp_l, (float*)disp_r, g->W, g->H, g->D, g->dmin,
+                       check_unique, one_minus_ratio, g->row_begin);
+}
+
+template <int DPL>
 static void launch_sum_wta(dim3 grid, hipStream_t st, const void* planes, size_t plane_bytes, int ndirs, const void* extras,
                            const void* row_extras, const void* row_extra_count, int row_cap, int accumulate, void* S,
                            void* disp_l, const sgmd_geom* g, int check_unique, float one_minus_ratio)
@@ -1626,6 +1839,29 @@ int sgmd_sum_wta(int ord, void* stream, const sgmd_geom* g, int ndirs, const voi
         return -1;
     }
 #undef SUM_ARGS
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sgmd_sum_wta_lr_supported(const sgmd_geom* g) { return g->Dp == 32 || g->Dp == 64 || g->Dp == 128; }
+
+int sgmd_sum_wta_lr(int ord, void* stream, const sgmd_geom* g, int ndirs, const void* planes, size_t plane_bytes,
+                    const void* extras, const void* row_extras, const void* row_extra_count, int row_cap, int accumulate,
+                    int store_S, int do_right, void* S, int check_unique, float one_minus_ratio, void* disp_l, void* disp_r)
+{
+    HIP_TRY(hipSetDevice(ord));
+    const dim3 grid(g->row_end - g->row_begin, g->B);
+    hipStream_t st = (hipStream_t)stream;
+#define SUMLR_ARGS grid, st, planes, plane_bytes, ndirs, extras, row_extras, row_extra_count, row_cap, accumulate, store_S, do_right, S, disp_l, disp_r, g, check_unique, one_minus_ratio
+    switch (g->Dp / 16) {
+    case 2: launch_sum_wta_lr<2>(SUMLR_ARGS); break;
+    case 4: launch_sum_wta_lr<4>(SUMLR_ARGS); break;
+    case 8: launch_sum_wta_lr<8>(SUMLR_ARGS); break;
+    default:
+        fprintf(stderr, "sgm_mi355x: fused sum/WTA needs Dp <= 128 (got %d)\n", g->Dp);
+        return -1;
+    }
+#undef SUMLR_ARGS
     HIP_TRY(hipGetLastError());
     return 0;
 }
