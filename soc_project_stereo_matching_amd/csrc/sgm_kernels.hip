@@ -872,18 +872,24 @@ __global__ __launch_bounds__(256) void sgm_sum_wta_k(const uint8_t* __restrict__
 // ============================================================================================
 template <int DPL, int STAGE>
 static __device__ __forceinline__ void sumlr_prefetch(CellVec<DPL> (&pre)[2][8], const uint8_t* planes, size_t plane_bytes,
-                                                      int ndirs, size_t off, bool live)
+                                                      int ndirs, size_t off)
 {
+    // always 8 unconditional loads (see SLOW below): with four paths the upper four re-read planes 0..3 and are
+    // masked out when they are added
 #pragma unroll
-    for (int d = 0; d < 8; ++d) {
-#pragma unroll
-        for (int k = 0; k < (DPL + 3) / 4; ++k) pre[STAGE][d].w[k] = 0;
-        if (live && d < ndirs) load_cells_nt<DPL>(planes + (size_t)d * plane_bytes + off, pre[STAGE][d]);
-    }
+    for (int d = 0; d < 8; ++d)
+        load_cells_nt<DPL>(planes + (size_t)(d < ndirs ? d : d - 4) * plane_bytes + off, pre[STAGE][d]);
 }
 
-template <int DPL>
-__global__ __launch_bounds__(256) void sgm_sum_wta_lr_k(const uint8_t* __restrict__ planes, size_t plane_bytes, int ndirs,
+// SLOW = the variant that may read (accumulate) or write (store_S) S.  The common one has no conditional global
+// access inside the loop at all: hipcc merges s_waitcnt counts over all control-flow paths, and a load behind a
+// condition or in a loop of unknown trip count makes it drain the two-iterations-deep plane prefetch (vmcnt(0))
+// every iteration -- which is why columns past the row end re-read the last column instead of being skipped, why
+// the right-view-only iterations after the last column are a loop of their own, and why the anomalous-line
+// visits of the row are staged in LDS up front.
+#define SUMLR_MAX_EXTRA 8
+template <int DPL, bool SLOW, int THREADS>
+__global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __restrict__ planes, size_t plane_bytes, int ndirs,
                                                         const uint8_t* __restrict__ extras,
                                                         const sgmd_row_extra* __restrict__ row_extras,
                                                         const int* __restrict__ row_extra_count, int row_cap,
@@ -894,8 +900,11 @@ __global__ __launch_bounds__(256) void sgm_sum_wta_lr_k(const uint8_t* __restric
 {
     constexpr int Dp = 16 * DPL;
     constexpr int LD = Dp + 2;
-    constexpr int R = Dp + 32;
+    constexpr int COLS = THREADS / 16;                                   // columns per iteration
+    constexpr int R = Dp + 2 * COLS;
     __shared__ unsigned short ring[R * LD];
+    __shared__ unsigned ex_val[SUMLR_MAX_EXTRA * (Dp / 4)];
+    __shared__ int ex_col[SUMLR_MAX_EXTRA];
 
     const int sub = threadIdx.x & 15;
     const int px = threadIdx.x >> 4;
@@ -906,50 +915,110 @@ __global__ __launch_bounds__(256) void sgm_sum_wta_lr_k(const uint8_t* __restric
     disp_l += (size_t)blockIdx.y * W * H;
     disp_r += (size_t)blockIdx.y * W * H;
     const size_t row_cells = (size_t)row * W * Dp;
-    const int n_extra = (ndirs > 4) ? row_extra_count[row] : 0;
+    const int n_extra = (ndirs > 4) ? min(row_extra_count[row], SUMLR_MAX_EXTRA) : 0;    // host: row_cap <= SUMLR_MAX_EXTRA
+    for (int t = threadIdx.x; t < n_extra * (Dp / 4); t += THREADS) {
+        const int j = t / (Dp / 4), w = t % (Dp / 4);
+        const sgmd_row_extra e = row_extras[row * row_cap + j];
+        if (w == 0) ex_col[j] = e.col_slot & 0xFFFF;
+        ex_val[t] = *reinterpret_cast<const unsigned*>(extras + ((size_t)(e.col_slot >> 16) * H + e.step) * Dp + w * 4);
+    }
+    __syncthreads();
 
-    // iterations: the last right pixel (W-1) completes with column W-1 + dmin + D-1; without the right view the
-    // row ends with its last column
-    const int last_col = do_right ? W - 1 + dmin + D - 1 : W - 1;
-    const int n_iter = last_col / 16 + 1;
+    // main iterations cover the image columns; the right view then needs dmin + D - 1 more (virtual) columns:
+    // its last pixel W-1 completes with column W-1 + dmin + D-1
+    const int n_main = (W + COLS - 1) / COLS;
+    const int n_iter = do_right ? (W - 1 + dmin + D - 1) / COLS + 1 : n_main;
+    const unsigned upper_mask = (ndirs > 4) ? 0xFFu : 0u;               // planes 4..7 count only with eight paths
 
+    auto cell_off = [&](int x) { return row_cells + (size_t)min(x, W - 1) * Dp + sub * DPL; };
     CellVec<DPL> pre[2][8];
-    sumlr_prefetch<DPL, 0>(pre, planes, plane_bytes, ndirs, row_cells + (size_t)px * Dp + sub * DPL, px < W);
-    sumlr_prefetch<DPL, 1>(pre, planes, plane_bytes, ndirs, row_cells + (size_t)(16 + px) * Dp + sub * DPL, 16 + px < W);
+    sumlr_prefetch<DPL, 0>(pre, planes, plane_bytes, ndirs, cell_off(px));
+    sumlr_prefetch<DPL, 1>(pre, planes, plane_bytes, ndirs, cell_off(COLS + px));
 
     int slot = px;                                                       // ring slot of this thread's column: x mod R
-    auto body = [&](int it, auto stage_tag) {
+
+    // right-view WTA of the pixel whose last column (disparity D-1) is column x, after the ring holds column x
+    auto right_view = [&](int x) {
+        __syncthreads();                                                 // the new columns are in the ring
+        const int xr = x - dmin - (D - 1);
+        int base = slot + R - (D - 1);                                   // ring slot of column xr + dmin = x - (D-1)
+        if (base >= R) base -= R;
+        unsigned key[DPL], val[DPL];
+        unsigned kmin = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) {
+            const int k = sub * DPL + i;
+            int sl = base + k;
+            if (sl >= R) sl -= R;
+            val[i] = ring[sl * LD + k];                                  // padding disparities hold 65535
+        }
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) {
+            const int k = sub * DPL + i;
+            key[i] = (k < D) ? ((val[i] << 16) | (unsigned)k) : 0xFFFFFFFFu;
+            kmin = min(kmin, key[i]);
+        }
+        const unsigned kbest = row_allmin<16>(kmin);
+        unsigned k2 = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) k2 = min(k2, key[i] == kbest ? 0xFFFFFFFFu : key[i]);
+        const unsigned ksecond = row_allmin<16>(k2);
+        const int dbest = (int)(kbest & 0xFFFFu);
+        unsigned nb = 0;                                                 // S[best-1] | S[best+1] << 16; a best at either end
+#pragma unroll                                                           // of the range is invalid anyway (ref :428)
+        for (int i = 0; i < DPL; ++i) {
+            const int k = sub * DPL + i;
+            if (k == dbest - 1) nb |= val[i];
+            if (k == dbest + 1) nb |= val[i] << 16;
+        }
+        nb = row_allor(nb);
+        if (xr >= 0 && xr < W && sub == 0) {
+            WtaState st;
+            st.m1 = kbest >> 16;
+            st.m2 = ksecond >> 16;
+            st.d1 = ((kbest >> 16) == 0xFFFFu) ? -1 : dbest;             // nothing beat 65535 (ref :381, strict '>')
+            st.c1 = nb & 0xFFFFu;
+            st.c2 = nb >> 16;
+            st.pv = 0; st.want_next = false;
+            disp_r[(size_t)row * W + xr] = wta_finish(st, D, dmin, check_unique, one_minus_ratio);
+        }
+    };
+    auto next_slot = [&]() {
+        slot += COLS;
+        if (slot >= R) slot -= R;
+    };
+
+    auto main_body = [&](int it, auto stage_tag) {
         constexpr int STAGE = decltype(stage_tag)::value;
-        const int x = it * 16 + px;
+        const int x = it * COLS + px;
         const bool inside = x < W;
-        const size_t off = row_cells + (size_t)x * Dp + sub * DPL;
+        const size_t off = cell_off(x);
         unsigned acc[DPL];
 #pragma unroll
         for (int i = 0; i < DPL; ++i) acc[i] = 0;
-        if (it * 16 < W) {                                               // wave-uniform: a column of the image
-            if (accumulate && inside) {                                  // Q14: S was not reset since the last frame
+        if (SLOW) {
+            if (accumulate) {                                            // Q14: S was not reset since the last frame
 #pragma unroll
                 for (int i = 0; i < DPL; ++i) acc[i] = S[off + i];
             }
+        }
 #pragma unroll
-            for (int d = 0; d < 8; ++d) {
+        for (int d = 0; d < 8; ++d) {
+            const unsigned m = (d < 4) ? 0xFFu : upper_mask;
 #pragma unroll
-                for (int i = 0; i < DPL; ++i) acc[i] += (pre[STAGE][d].w[i >> 2] >> (8 * (i & 3))) & 0xFF;
-            }
-            // refill this stage with the columns of iteration it + 2
-            {
-                const int xn = x + 32;
-                sumlr_prefetch<DPL, STAGE>(pre, planes, plane_bytes, ndirs, row_cells + (size_t)xn * Dp + sub * DPL, xn < W);
-            }
-            for (int j = 0; j < n_extra; ++j) {
-                const sgmd_row_extra e = row_extras[row * row_cap + j];
-                if (inside && (e.col_slot & 0xFFFF) == x) {
-                    CellVec<DPL> v;
-                    load_cells<DPL>(extras + ((size_t)(e.col_slot >> 16) * H + e.step) * Dp + sub * DPL, v);
+            for (int i = 0; i < DPL; ++i) acc[i] += (pre[STAGE][d].w[i >> 2] >> (8 * (i & 3))) & m;
+        }
+        sumlr_prefetch<DPL, STAGE>(pre, planes, plane_bytes, ndirs, cell_off(x + 2 * COLS));     // columns of iteration it + 2
+        for (int j = 0; j < n_extra; ++j) {
+            if (ex_col[j] == x) {                                        // second visit of an anomalous line (LDS)
 #pragma unroll
-                    for (int i = 0; i < DPL; ++i) acc[i] += (v.w[i >> 2] >> (8 * (i & 3))) & 0xFF;
+                for (int i = 0; i < DPL; ++i) {
+                    const int b = sub * DPL + i;
+                    acc[i] += (ex_val[j * (Dp / 4) + (b >> 2)] >> (8 * (b & 3))) & 0xFF;
                 }
             }
+        }
+        if (SLOW) {
             if (store_S && inside) {
                 unsigned short* dst = S + off;
 #pragma unroll
@@ -969,93 +1038,58 @@ __global__ __launch_bounds__(256) void sgm_sum_wta_lr_k(const uint8_t* __restric
             }
         }
         // ---- left-view WTA over the 16 lanes of the pixel (as in sgm_sum_wta_k) ----
-        if (it * 16 < W) {
-            unsigned key[DPL];
-            unsigned kmin = 0xFFFFFFFFu;
+        unsigned key[DPL];
+        unsigned kmin = 0xFFFFFFFFu;
 #pragma unroll
-            for (int i = 0; i < DPL; ++i) {
-                const int idx = sub * DPL + i;
-                key[i] = (idx < D) ? (((acc[i] & 0xFFFFu) << 16) | (unsigned)idx) : 0xFFFFFFFFu;
-                kmin = min(kmin, key[i]);
-            }
-            const unsigned kbest = row_allmin<16>(kmin);
-            unsigned k2 = 0xFFFFFFFFu;
-#pragma unroll
-            for (int i = 0; i < DPL; ++i) k2 = min(k2, key[i] == kbest ? 0xFFFFFFFFu : key[i]);
-            const unsigned ksecond = row_allmin<16>(k2);
-            const int dbest = (int)(kbest & 0xFFFFu);
-            unsigned nb = 0;
-#pragma unroll
-            for (int i = 0; i < DPL; ++i) {
-                const int idx = sub * DPL + i;
-                if (idx == dbest - 1) nb |= acc[i] & 0xFFFFu;
-                if (idx == dbest + 1) nb |= acc[i] << 16;
-            }
-            nb = row_allor(nb);
-            if (inside && sub == 0) {
-                WtaState st;
-                st.m1 = kbest >> 16;
-                st.m2 = ksecond >> 16;
-                st.d1 = (kbest == 0xFFFFFFFFu) ? -1 : dbest;
-                st.c1 = nb & 0xFFFFu;
-                st.c2 = nb >> 16;
-                st.pv = 0; st.want_next = false;
-                disp_l[(size_t)row * W + x] = wta_finish(st, D, dmin, check_unique, one_minus_ratio);
-            }
+        for (int i = 0; i < DPL; ++i) {
+            const int idx = sub * DPL + i;
+            key[i] = (idx < D) ? (((acc[i] & 0xFFFFu) << 16) | (unsigned)idx) : 0xFFFFFFFFu;
+            kmin = min(kmin, key[i]);
         }
-        if (do_right) {
-            __syncthreads();                                             // the 16 new columns are in the ring
-            // ---- right-view WTA of the pixel whose last column (disparity D-1) is this thread's column ----
-            const int xr = x - dmin - (D - 1);
-            // ring slot of column xr + dmin = x - (D-1)
-            int base = slot + R - (D - 1);
-            if (base >= R) base -= R;
-            unsigned key[DPL], val[DPL];
-            unsigned kmin = 0xFFFFFFFFu;
+        const unsigned kbest = row_allmin<16>(kmin);
+        unsigned k2 = 0xFFFFFFFFu;
 #pragma unroll
-            for (int i = 0; i < DPL; ++i) {
-                const int k = sub * DPL + i;
-                int sl = base + k;
-                if (sl >= R) sl -= R;
-                val[i] = ring[sl * LD + k];                              // padding disparities hold 65535
-            }
+        for (int i = 0; i < DPL; ++i) k2 = min(k2, key[i] == kbest ? 0xFFFFFFFFu : key[i]);
+        const unsigned ksecond = row_allmin<16>(k2);
+        const int dbest = (int)(kbest & 0xFFFFu);
+        unsigned nb = 0;
 #pragma unroll
-            for (int i = 0; i < DPL; ++i) {
-                const int k = sub * DPL + i;
-                key[i] = (k < D) ? ((val[i] << 16) | (unsigned)k) : 0xFFFFFFFFu;
-                kmin = min(kmin, key[i]);
-            }
-            const unsigned kbest = row_allmin<16>(kmin);
-            unsigned k2 = 0xFFFFFFFFu;
-#pragma unroll
-            for (int i = 0; i < DPL; ++i) k2 = min(k2, key[i] == kbest ? 0xFFFFFFFFu : key[i]);
-            const unsigned ksecond = row_allmin<16>(k2);
-            const int dbest = (int)(kbest & 0xFFFFu);
-            unsigned nb = 0;                                             // S[best-1] | S[best+1] << 16; a best at either end of
-#pragma unroll                                                           // the range is invalid anyway (ref :428)
-            for (int i = 0; i < DPL; ++i) {
-                const int k = sub * DPL + i;
-                if (k == dbest - 1) nb |= val[i];
-                if (k == dbest + 1) nb |= val[i] << 16;
-            }
-            nb = row_allor(nb);
-            if (xr >= 0 && xr < W && sub == 0) {
-                WtaState st;
-                st.m1 = kbest >> 16;
-                st.m2 = ksecond >> 16;
-                st.d1 = ((kbest >> 16) == 0xFFFFu) ? -1 : dbest;         // nothing beat 65535 (ref :381, strict '>')
-                st.c1 = nb & 0xFFFFu;
-                st.c2 = nb >> 16;
-                st.pv = 0; st.want_next = false;
-                disp_r[(size_t)row * W + xr] = wta_finish(st, D, dmin, check_unique, one_minus_ratio);
-            }
+        for (int i = 0; i < DPL; ++i) {
+            const int idx = sub * DPL + i;
+            if (idx == dbest - 1) nb |= acc[i] & 0xFFFFu;
+            if (idx == dbest + 1) nb |= acc[i] << 16;
         }
-        slot += 16;
-        if (slot >= R) slot -= R;
+        nb = row_allor(nb);
+        if (inside && sub == 0) {
+            WtaState st;
+            st.m1 = kbest >> 16;
+            st.m2 = ksecond >> 16;
+            st.d1 = (kbest == 0xFFFFFFFFu) ? -1 : dbest;
+            st.c1 = nb & 0xFFFFu;
+            st.c2 = nb >> 16;
+            st.pv = 0; st.want_next = false;
+            disp_l[(size_t)row * W + x] = wta_finish(st, D, dmin, check_unique, one_minus_ratio);
+        }
+        if (do_right) right_view(x);
+        next_slot();
     };
-    for (int it = 0; it < n_iter; it += 2) {
-        body(it, std::integral_constant<int, 0>{});
-        if (it + 1 < n_iter) body(it + 1, std::integral_constant<int, 1>{});
+
+    int it = 0;
+    for (; it + 1 < n_main; it += 2) {
+        main_body(it, std::integral_constant<int, 0>{});
+        main_body(it + 1, std::integral_constant<int, 1>{});
+    }
+    if (it < n_main) {
+        main_body(it, std::integral_constant<int, 0>{});
+        ++it;
+    }
+    // ---- columns past the image: only the right view is still working (no global loads) ----
+    for (; it < n_iter; ++it) {
+        unsigned* dst = reinterpret_cast<unsigned*>(&ring[slot * LD + sub * DPL]);
+#pragma unroll
+        for (int i = 0; i < DPL; i += 2) dst[i >> 1] = 0xFFFFFFFFu;
+        right_view(it * COLS + px);
+        next_slot();
     }
 }
 
@@ -1591,16 +1625,20 @@ static void launch_aggregate(const AggArgs& a, int blocks, bool pad, bool h32, h
     else     hipLaunchKernelGGL((sgm_aggregate_k<DPL, false, LPP, false>), dim3(blocks), dim3(64), 0, st, a);
 }
 
-template <int DPL>
+template <int DPL, int THREADS>
 static void launch_sum_wta_lr(dim3 grid, hipStream_t st, const void* planes, size_t plane_bytes, int ndirs, const void* extras,
                               const void* row_extras, const void* row_extra_count, int row_cap, int accumulate, int store_S,
                               int do_right, void* S, void* disp_l, void* disp_r, const sgmd_geom* g, int check_unique,
                               float one_minus_ratio)
 {
-    hipLaunchKernelGGL((sgm_sum_wta_lr_k<DPL>), grid, dim3(256), 0, st, (const uint8_t*)planes, plane_bytes, ndirs,
-                       (const uint8_t*)extras, (const sgmd_row_extra*)row_extras, (const int*)row_extra_count, row_cap,
-                       accumulate, store_S, do_right, (uint16_t*)S, (float*)disp_l, (float*)disp_r, g->W, g->H, g->D, g->dmin,
-                       check_unique, one_minus_ratio, g->row_begin);
+#define SUMLR_CALL(SLOW)                                                                                              \
+    hipLaunchKernelGGL((sgm_sum_wta_lr_k<DPL, SLOW, THREADS>), grid, dim3(THREADS), 0, st, (const uint8_t*)planes, plane_bytes, ndirs, \
+                       (const uint8_t*)extras, (const sgmd_row_extra*)row_extras, (const int*)row_extra_count, row_cap,  \
+                       accumulate, store_S, do_right, (uint16_t*)S, (float*)disp_l, (float*)disp_r, g->W, g->H, g->D,    \
+                       g->dmin, check_unique, one_minus_ratio, g->row_begin)
+    if (accumulate || store_S) SUMLR_CALL(true);
+    else SUMLR_CALL(false);
+#undef SUMLR_CALL
 }
 
 template <int DPL>
@@ -1843,7 +1881,10 @@ int sgmd_sum_wta(int ord, void* stream, const sgmd_geom* g, int ndirs, const voi
     return 0;
 }
 
-int sgmd_sum_wta_lr_supported(const sgmd_geom* g) { return g->Dp == 32 || g->Dp == 64 || g->Dp == 128; }
+int sgmd_sum_wta_lr_supported(const sgmd_geom* g, int row_cap)
+{
+    return (g->Dp == 32 || g->Dp == 64 || g->Dp == 128) && row_cap <= SUMLR_MAX_EXTRA;
+}
 
 int sgmd_sum_wta_lr(int ord, void* stream, const sgmd_geom* g, int ndirs, const void* planes, size_t plane_bytes,
                     const void* extras, const void* row_extras, const void* row_extra_count, int row_cap, int accumulate,
@@ -1854,9 +1895,9 @@ int sgmd_sum_wta_lr(int ord, void* stream, const sgmd_geom* g, int ndirs, const 
     hipStream_t st = (hipStream_t)stream;
 #define SUMLR_ARGS grid, st, planes, plane_bytes, ndirs, extras, row_extras, row_extra_count, row_cap, accumulate, store_S, do_right, S, disp_l, disp_r, g, check_unique, one_minus_ratio
     switch (g->Dp / 16) {
-    case 2: launch_sum_wta_lr<2>(SUMLR_ARGS); break;
-    case 4: launch_sum_wta_lr<4>(SUMLR_ARGS); break;
-    case 8: launch_sum_wta_lr<8>(SUMLR_ARGS); break;
+    case 2: launch_sum_wta_lr<2, 256>(SUMLR_ARGS); break;
+    case 4: launch_sum_wta_lr<4, 256>(SUMLR_ARGS); break;
+    case 8: launch_sum_wta_lr<8, 256>(SUMLR_ARGS); break;   // (512 threads = 32 columns per iteration measured the same)
     default:
         fprintf(stderr, "sgm_mi355x: fused sum/WTA needs Dp <= 128 (got %d)\n", g->Dp);
         return -1;
