@@ -100,8 +100,14 @@ def main():
     # one process per GPU; if the launcher already narrowed the visible devices to one per rank, that one is device 0
     local_rank = local_rank if torch.cuda.device_count() > local_rank else 0
     torch.cuda.set_device(local_rank)
+    # nccl (= RCCL) on a multi-GPU node; SGM_BENCH_BACKEND=gloo rehearses the same multi-process path on a box whose
+    # ranks share one GPU (RCCL refuses two ranks on one device)
+    backend = os.environ.get("SGM_BENCH_BACKEND", "nccl")
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
 
     w, h, d, seed, golden = WORKLOADS[args.workload]
     opt = S.default_option(d)
@@ -152,7 +158,7 @@ def main():
         i.synchronize()                                  # collects the HIP-event stage times of each instance's last frame
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
