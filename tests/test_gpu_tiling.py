@@ -70,6 +70,25 @@ def test_tiles_reproduce_the_single_gpu_result(oracle, case):
             e.close()
 
 
+def test_kitti_frame_in_eight_tiles_matches_the_reference_digest(golden_cases):
+    """BASELINE.json configs[3] shape: a 1242x375 D=128 frame cut into 8 row tiles (47 / 46 rows) as on an 8-GPU
+    node; the final map must hash to the digest the REFERENCE produced for this frame (tests/golden/cases.json)."""
+    import torch
+    import soc_project_stereo_matching_amd as S
+    from oracle.pyoracle import sha
+    from soc_project_stereo_matching_amd.tiling import match_tiled_in_process
+    case = golden_cases["c2_kitti_1242x375_d128"]
+    w, h, d = case["w"], case["h"], case["d"]
+    left, right = S.synth_pair(w, h, d, case["seed"])
+    engines = _engines(w, h, S.default_option(d), 8)
+    try:
+        got = match_tiled_in_process(engines, torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda())
+        assert sha(got.cpu().numpy()) == case["sha256"]["final"]
+    finally:
+        for e in engines:
+            e.close()
+
+
 def test_tiles_four_path_mode(oracle):
     import torch
     from oracle.pyoracle import default_option
