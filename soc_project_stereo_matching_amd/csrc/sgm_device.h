@@ -42,7 +42,8 @@ typedef struct {
     int Dp;            /* padded cell stride of the volumes: 16 * DPL >= D */
     int DPL;           /* disparities per lane in the aggregation kernel (2,4,8,12,16,32) */
     int LPP;           /* lanes per pixel in the aggregation kernel: 16 (4 lines per wave) or 8 (8 lines); Dp = LPP*DPL */
-    int H32;           /* 1: horizontal lines use 32 lanes per pixel (2 lines per wave; needs Dp/32 in {2,4,8,16}) */
+    int HL;            /* lanes per pixel of the horizontal lines: 0 = LPP, or 32 / 64 (2 / 1 lines per wave; needs
+                          Dp/HL in {2,4,8,16}): the launcher falls back to LPP where the combination does not exist */
     int dmin;          /* min_disparity */
     int B;             /* frames per launch (batch): every buffer is [B][...] frame-major, every kernel
                           processes all B frames */

@@ -357,18 +357,24 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
     s->g.Dp = 16 * s->g.DPL;
     /* a batch of frames is VALU-bound: 8 lanes per pixel (twice the disparities per lane, same Dp) spends the
      * fewest instructions per cell; a single frame keeps 16 lanes per pixel for the shorter serial step (measured
-     * at KITTI size, one frame: 16 lanes + H32 0.34 ms, 8 lanes + H32 0.39 ms, 8 lanes 0.59 ms) */
+     * at KITTI size, one frame: 16 lanes + 32-lane horizontals 0.35 ms, 8 lanes + 32-lane horizontals 0.39 ms, 8 lanes 0.59 ms) */
     {
         const char* e = getenv("SGM_LANES_PER_PIXEL");
         const int want = (e && *e) ? atoi(e) : (s->batch >= 2 ? 8 : 16);
         if (want == 8 && s->g.DPL >= 2 && s->g.DPL <= 8 && s->g.DPL != 6) { s->g.LPP = 8; s->g.DPL *= 2; }
     }
-    /* one frame per launch: the horizontal lines (W-1 serial steps) are the critical path -> 32 lanes per pixel for them */
+    /* one frame per launch: the horizontal lines (W-1 serial steps) are the longest chains of the launch -> spread each
+     * pixel of those over 32 lanes (2 lines per wave).  64 lanes (SGM_HL=64, one line per wave) measures the same at
+     * KITTI size (0.351 vs 0.349 ms): with one frame the launch is then bound by total VALU issue at ~2 waves per SIMD */
     {
-        const char* e = getenv("SGM_H32");
-        const int per = s->g.Dp / 32;
-        const int can = (s->g.Dp % 32 == 0) && (per == 2 || per == 4 || per == 8 || per == 16);
-        s->g.H32 = can && ((e && *e) ? atoi(e) != 0 : s->batch == 1);
+        const char* e = getenv("SGM_HL");
+        const int ok64 = (s->g.Dp % 64 == 0) && (s->g.Dp / 64 == 2 || s->g.Dp / 64 == 4 || s->g.Dp / 64 == 8);
+        const int ok32 = (s->g.Dp % 32 == 0) && (s->g.Dp / 32 == 2 || s->g.Dp / 32 == 4 || s->g.Dp / 32 == 8 || s->g.Dp / 32 == 16);
+        int want = (e && *e) ? atoi(e) : (s->batch == 1 ? 32 : 0);
+        if (want == 64 && !ok64) want = 32;
+        if (want == 32 && !ok32) want = 0;
+        if (want == s->g.LPP) want = 0;
+        s->g.HL = want;
     }
     s->g.dmin = option->min_disparity;
     s->g.B = s->batch;

@@ -75,6 +75,11 @@ static __device__ __forceinline__ unsigned row_allmin(unsigned v)
         const auto sw = __builtin_amdgcn_permlane16_swap(v, v, false, false);
         v = min(sw[0], sw[1]);
     }
+    if (LPP == 64) {                                              // one pixel per wave: the result is wave-uniform (SGPR)
+        const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+        const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+        v = min(min(a, b), min(c, d));
+    }
     return v;
 }
 
@@ -341,7 +346,7 @@ static __device__ __forceinline__ unsigned agg_step(const us2 (&C)[DPL / 2], us2
     const us2 mp = as_p(min_prev | (min_prev << 16));
     // d-1 / d+1 neighbours across the lane boundary; 255 where there is none (ref :260-263)
     unsigned from_left, from_right;
-    if (LPP == 32) {                                    // a pixel spans two DPP rows: shift across the whole wave
+    if (LPP >= 32) {                                    // a pixel spans several DPP rows: shift across the whole wave
         from_left = dpp_mov<0x138 /* wave_shr:1 */>(0x00FF00FFu, as_u(Lp[NP - 1]));
         from_right = dpp_mov<0x130 /* wave_shl:1 */>(0x00FF00FFu, as_u(Lp[0]));
     } else {
@@ -387,7 +392,7 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
                                                    int dir, int grp)
 {
     constexpr int NP = DPL / 2;
-    constexpr int PF = (LPP == 32) ? 4 : 2;                              // prefetch depth (steps): 2 keeps the 8-lines-per-wave kernel at 8 waves/SIMD; the latency-critical 32-lane lines look further ahead
+    constexpr int PF = (LPP >= 32) ? 4 : 2;                              // prefetch depth (steps): 2 keeps the 8-lines-per-wave kernel at 8 waves/SIMD; the latency-critical 32-lane lines look further ahead
     const int lane = threadIdx.x;
     const int dx = a.dx[dir], dy = a.dy[dir];
     const int W = a.W, H = a.H, Dp = a.Dp;
@@ -680,7 +685,7 @@ static __device__ __forceinline__ void agg_anomalous(const AggArgs& a, const Agg
     }
 }
 
-template <int DPL, bool PAD, int LPP, bool H32>
+template <int DPL, bool PAD, int LPP, int HL>
 __global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
 {
     __shared__ unsigned short lut_s[256];
@@ -710,11 +715,11 @@ __global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
     // the horizontal lines are the longest serial chains of the launch (W-1 dependent steps): their waves
     // get issue priority over the shorter vertical/diagonal ones sharing the SIMD, also across frames in flight
     if (a.dy[dir] == 0) __builtin_amdgcn_s_setprio(3);
-    // H32 (single-frame mode): the horizontal lines are the critical path of the launch (W-1 serial steps), so
+    // HL (single-frame mode): the horizontal lines are the critical path of the launch (W-1 serial steps), so
     // they get 32 lanes per pixel -- fewer disparities per lane, the shortest step -- while the vertical and
     // diagonal lines keep the lane count that costs the fewest instructions per cell
     if (a.dy[dir] == 0) {
-        if constexpr (H32) agg_regular<DPL * LPP / 32, PAD, 32, AGG_H>(a, fr, lut_s, dir, grp);
+        if constexpr (HL != 0) agg_regular<DPL * LPP / HL, PAD, HL, AGG_H>(a, fr, lut_s, dir, grp);
         else               agg_regular<DPL, PAD, LPP, AGG_H>(a, fr, lut_s, dir, grp);
     }
     else if (a.dx[dir] == 0) agg_regular<DPL, PAD, LPP, AGG_V>(a, fr, lut_s, dir, grp);
@@ -1609,20 +1614,24 @@ extern "C" size_t sgmd_census_slack(const sgmd_geom* g)
     return (((size_t)g->dmin + g->Dp + 8) * sizeof(uint32_t) + 255) & ~(size_t)255;
 }
 
-template <int DPL, int LPP>
-static void launch_aggregate(const AggArgs& a, int blocks, bool pad, bool h32, hipStream_t st)
+template <int DPL, int LPP, int HL>
+static bool launch_aggregate_hl(const AggArgs& a, int blocks, bool pad, hipStream_t st)
 {
-    constexpr bool can_h32 = (DPL * LPP / 32 == 2 || DPL * LPP / 32 == 4 || DPL * LPP / 32 == 8 || DPL * LPP / 32 == 16) &&
-                             (DPL * LPP % 32 == 0);
-    if constexpr (can_h32) {
-        if (h32) {
-            if (pad) hipLaunchKernelGGL((sgm_aggregate_k<DPL, true, LPP, true>), dim3(blocks), dim3(64), 0, st, a);
-            else     hipLaunchKernelGGL((sgm_aggregate_k<DPL, false, LPP, true>), dim3(blocks), dim3(64), 0, st, a);
-            return;
-        }
+    constexpr int per = (HL != 0) ? DPL * LPP / HL : DPL;                 // disparities per lane on the horizontal lines
+    constexpr bool ok = (HL == 0) || ((DPL * LPP) % HL == 0 && (per == 2 || per == 4 || per == 8 || per == 16) && HL != LPP);
+    if constexpr (ok) {
+        if (pad) hipLaunchKernelGGL((sgm_aggregate_k<DPL, true, LPP, HL>), dim3(blocks), dim3(64), 0, st, a);
+        else     hipLaunchKernelGGL((sgm_aggregate_k<DPL, false, LPP, HL>), dim3(blocks), dim3(64), 0, st, a);
+        return true;
     }
-    if (pad) hipLaunchKernelGGL((sgm_aggregate_k<DPL, true, LPP, false>), dim3(blocks), dim3(64), 0, st, a);
-    else     hipLaunchKernelGGL((sgm_aggregate_k<DPL, false, LPP, false>), dim3(blocks), dim3(64), 0, st, a);
+    return false;
+}
+template <int DPL, int LPP>
+static void launch_aggregate(const AggArgs& a, int blocks, bool pad, int hl, hipStream_t st)
+{
+    if (hl == 64 && launch_aggregate_hl<DPL, LPP, 64>(a, blocks, pad, st)) return;
+    if (hl == 32 && launch_aggregate_hl<DPL, LPP, 32>(a, blocks, pad, st)) return;
+    launch_aggregate_hl<DPL, LPP, 0>(a, blocks, pad, st);
 }
 
 template <int DPL, int THREADS>
@@ -1825,7 +1834,7 @@ int sgmd_aggregate(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* 
         a.block_begin[d] = blocks;
         if (d < paths->ndirs && ((paths->dir_mask >> d) & 1)) {
             const int nlines = (paths->dy[d] == 0) ? g->row_end - g->row_begin : g->W;
-            const int lines_per_wave = (paths->dy[d] == 0 && g->H32) ? 2 : 64 / g->LPP;
+            const int lines_per_wave = 64 / ((paths->dy[d] == 0 && g->HL) ? g->HL : g->LPP);
             blocks += (nlines + lines_per_wave - 1) / lines_per_wave;
         }
     }
@@ -1840,15 +1849,15 @@ int sgmd_aggregate(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* 
     // per cell and is what a batch of frames (VALU-bound) uses.
     const int key = g->LPP * 100 + g->DPL;
     switch (key) {
-    case 1602: launch_aggregate<2, 16>(a, blocks, pad, g->H32 != 0, st); break;
-    case 1604: launch_aggregate<4, 16>(a, blocks, pad, g->H32 != 0, st); break;
-    case 1608: launch_aggregate<8, 16>(a, blocks, pad, g->H32 != 0, st); break;
-    case 1612: launch_aggregate<12, 16>(a, blocks, pad, g->H32 != 0, st); break;
-    case 1616: launch_aggregate<16, 16>(a, blocks, pad, g->H32 != 0, st); break;
-    case 1632: launch_aggregate<32, 16>(a, blocks, pad, g->H32 != 0, st); break;
-    case 804:  launch_aggregate<4, 8>(a, blocks, pad, g->H32 != 0, st); break;
-    case 808:  launch_aggregate<8, 8>(a, blocks, pad, g->H32 != 0, st); break;
-    case 816:  launch_aggregate<16, 8>(a, blocks, pad, g->H32 != 0, st); break;
+    case 1602: launch_aggregate<2, 16>(a, blocks, pad, g->HL, st); break;
+    case 1604: launch_aggregate<4, 16>(a, blocks, pad, g->HL, st); break;
+    case 1608: launch_aggregate<8, 16>(a, blocks, pad, g->HL, st); break;
+    case 1612: launch_aggregate<12, 16>(a, blocks, pad, g->HL, st); break;
+    case 1616: launch_aggregate<16, 16>(a, blocks, pad, g->HL, st); break;
+    case 1632: launch_aggregate<32, 16>(a, blocks, pad, g->HL, st); break;
+    case 804:  launch_aggregate<4, 8>(a, blocks, pad, g->HL, st); break;
+    case 808:  launch_aggregate<8, 8>(a, blocks, pad, g->HL, st); break;
+    case 816:  launch_aggregate<16, 8>(a, blocks, pad, g->HL, st); break;
     default:
         fprintf(stderr, "sgm_mi355x: unsupported lanes-per-pixel/DPL combination %d/%d\n", g->LPP, g->DPL);
         return -1;
