@@ -229,6 +229,57 @@ def test_lane_layouts_of_the_aggregation_kernel(oracle, hl, lanes, monkeypatch):
         i.close()
 
 
+def _speckle_maps(rng, h, w):
+    """Disparity maps that stress the connected-component labelling: long straight tile edges, thin stripes,
+    holes, one giant component, noise around the |delta| <= 1 link threshold."""
+    inf = np.float32(np.inf)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    maps = {}
+    maps["flat"] = np.full((h, w), 7.25, np.float32)
+    maps["ramp"] = (xx * 0.4 + yy * 0.3).astype(np.float32)                    # every neighbour linked
+    maps["steps64"] = (np.floor(xx / 64) * 3 + np.floor(yy / 16) * 5).astype(np.float32)   # edges ON the tile grid
+    maps["steps63"] = (np.floor((xx + 1) / 63) * 3 + np.floor((yy + 3) / 17) * 5).astype(np.float32)
+    maps["stripes_v"] = ((xx.astype(np.int32) % 3) * 2.5).astype(np.float32)
+    maps["stripes_h"] = ((yy.astype(np.int32) % 2) * 4.0).astype(np.float32)
+    maps["checker"] = (((xx.astype(np.int32) // 5 + yy.astype(np.int32) // 3) % 2) * 9.0).astype(np.float32)
+    noise = rng.random((h, w), dtype=np.float32)
+    maps["noise_thr"] = (10 + noise * 2.2).astype(np.float32)                  # links flip around the threshold
+    holes = (xx * 0.2).astype(np.float32)
+    holes[rng.random((h, w)) < 0.3] = inf
+    maps["holes"] = holes
+    diag = np.where((xx.astype(np.int32) + yy.astype(np.int32)) % 7 == 0, np.float32(50), inf).astype(np.float32)
+    maps["diagonals"] = diag                                                   # 8-connectivity only
+    blobs = np.floor(rng.random((h // 8 + 1, w // 8 + 1)) * 6).astype(np.float32).repeat(8, 0).repeat(8, 1)[:h, :w] * 3
+    blobs[rng.random((h, w)) < 0.05] = inf
+    maps["blobs"] = np.ascontiguousarray(blobs)
+    return maps
+
+
+@pytest.mark.parametrize("tile_rows", ["16", "32", "64"])
+@pytest.mark.parametrize("shape", [(64, 16), (65, 33), (200, 150), (257, 130), (130, 70), (640, 48)])
+def test_speckle_and_median_on_crafted_maps(oracle, shape, tile_rows, monkeypatch):
+    """Speckle removal (two-level union-find with implied-union skipping) + in-place median on crafted disparity
+    maps, through sgm_tile_post (the library's whole-frame post-filter entry) against the oracle's BFS."""
+    import torch
+    import soc_project_stereo_matching_amd as S
+    w, h = shape
+    monkeypatch.setenv("SGM_SPECKLE_TILE_ROWS", tile_rows)
+    rng = np.random.default_rng(w * 1000 + h)
+    i = S.SGMInstance(0)
+    try:
+        for min_area in (1, 9, 50, 700, 65535):
+            opt = S.default_option(16, min_speckle_area=min_area)
+            assert i.reset(w, h, opt)
+            for name, m in _speckle_maps(rng, h, w).items():
+                want = oracle.median(oracle.remove_speckles(m.copy(), min_area))
+                t = torch.from_numpy(m.copy()).cuda()
+                torch.cuda.synchronize()
+                assert i.tile_post(t.data_ptr()) and i.synchronize()
+                assert_same(t.cpu().numpy(), want, f"{name} {w}x{h} min_area={min_area}")
+    finally:
+        i.close()
+
+
 def _big_cases():
     import json
     import os
