@@ -222,6 +222,20 @@ def main():
                     per_frame = json.load(f).get(args.workload, {}).get("sgm_aggregate_k")
                 if per_frame:
                     roofline["traffic"] = int(per_frame) * B
+        # the other heavy kernel: cost sum + both WTAs, a pure HBM stream of the 8 planes (measured bytes, PMC)
+        sum_roofline = None
+        sum_ms = stage_ms.get("sum")
+        if sum_ms and os.path.exists(os.path.join(ROOT, "profiles", "hbm_traffic.json")):
+            with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+                wl = json.load(f).get(args.workload, {})
+            fused = wl.get("per_frame_fused_sum_wta", {}).get("sgm_sum_wta_lr_k")
+            if fused and h * B >= 1024 and d <= 128:   # what the library's choice of the fused kernel needs
+                nbytes = int(fused["hbm_bytes"]) * B
+                sum_roofline = {"bound": "hbm", "kernel": "sgm_sum_wta_lr_k", "achieved": round(nbytes / (sum_ms * 1e-3) / 1e9, 1),
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / (sum_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "traffic": nbytes, "avg_launch_ms": round(sum_ms, 4), "min_launch_ms": round(stage_min["sum"], 4),
+                                "note": "bytes = measured HBM traffic (8 planes read once); with a second batch in flight the "
+                                        "launch shares HBM with the other batch's aggregation"}
         frame_bytes = cells * (5 * PATHS + 3)
         steps_frames = args.steps * B
         line = {
@@ -237,6 +251,7 @@ def main():
                        "frames_per_gpu": args.steps * B, "batches_in_flight_per_gpu": n_inst,
                        "sharding": "independent frames per rank, no collective"},
             "roofline": roofline,
+            "roofline_sum_wta": sum_roofline,
             "frame_roofline": {"algorithmic_bytes_per_frame": frame_bytes,
                                "achieved_GBps_per_gpu": round(frame_bytes * steps_frames / elapsed / 1e9, 1),
                                "frac_per_gpu": round(frame_bytes * steps_frames / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
