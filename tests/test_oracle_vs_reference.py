@@ -26,6 +26,18 @@ def _cases():
             # SemiGlobalMatching.c:432-435) and segfaults: undefined behaviour, not a parity target
             kw["is_check_unique"] = True
         out.append((w, h, dmin, dmin + d, 1000 + k, kw))
+    # a second draw with large disparity ranges (padded and unpadded volumes, every lane layout of the GPU kernels)
+    rng2 = np.random.RandomState(20261005)
+    for k in range(20):
+        w = int(rng2.randint(6, 300))
+        h = int(rng2.randint(6, 90))
+        d = int(rng2.choice([65, 96, 100, 127, 128, 129, 160, 192, 200, 255, 256]))
+        dmin = int(rng2.choice([0, 0, 2, 7]))
+        kw = dict(p1=int(rng2.choice([0, 5, 10, 40])), p2_init=int(rng2.choice([0, 30, 150, 400])),
+                  is_check_unique=True, uniqueness_ratio=float(rng2.choice([0.99, 0.9])),
+                  is_check_lr=bool(rng2.rand() < 0.8), lrcheck_thres=float(rng2.choice([1.0, 0.5])),
+                  is_remove_speckles=bool(rng2.rand() < 0.8), min_speckle_area=int(rng2.choice([5, 20, 50])))
+        out.append((w, h, dmin, dmin + d, 2000 + k, kw))
     # hand-picked corners: negative penalties, the census no-op sizes, one-row / one-column images
     out += [(40, 20, 0, 16, 1, dict(p1=-7, p2_init=120)), (40, 20, 0, 16, 2, dict(p1=12, p2_init=-300)),
             (40, 20, 0, 16, 3, dict(p1=32767, p2_init=32767)), (5, 30, 0, 4, 4, {}), (30, 5, 0, 4, 5, {}),
