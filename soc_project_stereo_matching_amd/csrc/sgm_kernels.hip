@@ -907,6 +907,7 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
     constexpr int LD = Dp + 2;
     constexpr int COLS = THREADS / 16;                                   // columns per iteration
     constexpr int R = Dp + 2 * COLS;
+    static_assert(R % COLS == 0, "a ring slot must always belong to the same px");
     __shared__ unsigned short ring[R * LD];
     __shared__ unsigned ex_val[SUMLR_MAX_EXTRA * (Dp / 4)];
     __shared__ int ex_col[SUMLR_MAX_EXTRA];
@@ -964,26 +965,27 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
             kmin = min(kmin, key[i]);
         }
         const unsigned kbest = row_allmin<16>(kmin);
+        // runner-up: keys are distinct (they carry d), so key - kbest - 1 (mod 2^32) sends the best to the top
+        // and keeps the order of all others
+        const unsigned nbest = ~kbest;
         unsigned k2 = 0xFFFFFFFFu;
 #pragma unroll
-        for (int i = 0; i < DPL; ++i) k2 = min(k2, key[i] == kbest ? 0xFFFFFFFFu : key[i]);
-        const unsigned ksecond = row_allmin<16>(k2);
+        for (int i = 0; i < DPL; ++i) k2 = min(k2, key[i] + nbest);
+        const unsigned ksecond = row_allmin<16>(k2) + kbest + 1;
         const int dbest = (int)(kbest & 0xFFFFu);
-        unsigned nb = 0;                                                 // S[best-1] | S[best+1] << 16; a best at either end
-#pragma unroll                                                           // of the range is invalid anyway (ref :428)
-        for (int i = 0; i < DPL; ++i) {
-            const int k = sub * DPL + i;
-            if (k == dbest - 1) nb |= val[i];
-            if (k == dbest + 1) nb |= val[i] << 16;
-        }
-        nb = row_allor(nb);
         if (xr >= 0 && xr < W && sub == 0) {
+            // S[best-1], S[best+1] straight from the ring (a best at either end of the range is invalid anyway,
+            // ref :428: clamp the index, the value is not used)
+            const int km = max(dbest - 1, 0), kp = min(dbest + 1, Dp - 1);
+            int sm = base + km, sp = base + kp;
+            if (sm >= R) sm -= R;
+            if (sp >= R) sp -= R;
             WtaState st;
             st.m1 = kbest >> 16;
             st.m2 = ksecond >> 16;
             st.d1 = ((kbest >> 16) == 0xFFFFu) ? -1 : dbest;             // nothing beat 65535 (ref :381, strict '>')
-            st.c1 = nb & 0xFFFFu;
-            st.c2 = nb >> 16;
+            st.c1 = ring[sm * LD + km];
+            st.c2 = ring[sp * LD + kp];
             st.pv = 0; st.want_next = false;
             disp_r[(size_t)row * W + xr] = wta_finish(st, D, dmin, check_unique, one_minus_ratio);
         }
@@ -1032,7 +1034,9 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
             }
         }
         // ---- this column's S vector into the ring (65535 outside the image / the disparity range) ----
-        if (do_right) {
+        // (also without a right view: the left view fetches S[best +- 1] from here.  A column's slot is only ever
+        // written by the wave that owns px = slot mod 16 -- R is a multiple of 16 -- so that read-back needs no barrier)
+        {
             unsigned* dst = reinterpret_cast<unsigned*>(&ring[slot * LD + sub * DPL]);
 #pragma unroll
             for (int i = 0; i < DPL; i += 2) {
@@ -1052,26 +1056,21 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
             kmin = min(kmin, key[i]);
         }
         const unsigned kbest = row_allmin<16>(kmin);
+        const unsigned nbest = ~kbest;                                   // runner-up as in right_view()
         unsigned k2 = 0xFFFFFFFFu;
 #pragma unroll
-        for (int i = 0; i < DPL; ++i) k2 = min(k2, key[i] == kbest ? 0xFFFFFFFFu : key[i]);
-        const unsigned ksecond = row_allmin<16>(k2);
+        for (int i = 0; i < DPL; ++i) k2 = min(k2, key[i] + nbest);
+        const unsigned ksecond = row_allmin<16>(k2) + kbest + 1;
         const int dbest = (int)(kbest & 0xFFFFu);
-        unsigned nb = 0;
-#pragma unroll
-        for (int i = 0; i < DPL; ++i) {
-            const int idx = sub * DPL + i;
-            if (idx == dbest - 1) nb |= acc[i] & 0xFFFFu;
-            if (idx == dbest + 1) nb |= acc[i] << 16;
-        }
-        nb = row_allor(nb);
+        asm volatile("" ::: "memory");                                   // the wave's ring writes above stay above
         if (inside && sub == 0) {
+            const int km = max(dbest - 1, 0), kp = min(dbest + 1, Dp - 1);
             WtaState st;
             st.m1 = kbest >> 16;
             st.m2 = ksecond >> 16;
             st.d1 = (kbest == 0xFFFFFFFFu) ? -1 : dbest;
-            st.c1 = nb & 0xFFFFu;
-            st.c2 = nb >> 16;
+            st.c1 = ring[slot * LD + km];                                // S[best-1], S[best+1] (unused when best is at an end)
+            st.c2 = ring[slot * LD + kp];
             st.pv = 0; st.want_next = false;
             disp_l[(size_t)row * W + x] = wta_finish(st, D, dmin, check_unique, one_minus_ratio);
         }
