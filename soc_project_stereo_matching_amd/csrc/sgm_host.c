@@ -434,10 +434,10 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
     s->s_pending = false;
     {
         const char* e = getenv("SGM_FUSED_WTA");
-        /* one workgroup per image row: worth it once there are enough rows in a launch to fill the GPU (a single
-         * KITTI frame has 375: 0.20 ms against 0.16 ms for the two separate kernels; a batch of 8: 0.11 against 0.16) */
-        const long rows_per_launch = (long)(s->g.row_end - s->g.row_begin) * s->g.B;
-        const int want = (e && *e) ? atoi(e) != 0 : rows_per_launch >= 1024;
+        /* one workgroup per image row segment (the launcher cuts rows into up to 4 segments when a launch has few rows);
+         * at KITTI size: a batch of 8 frames 0.093 ms per frame against 0.115 + 0.043 for the two separate kernels, a
+         * single frame 0.144 against 0.163 */
+        const int want = (e && *e) ? atoi(e) != 0 : 1;
         s->fused_wta = sgmd_sum_wta_lr_supported(&s->g, s->row_cap) && want;
     }
     s->have_ms = false;

@@ -901,7 +901,7 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
                                                         int accumulate, int store_S, int do_right,
                                                         uint16_t* __restrict__ S, float* __restrict__ disp_l,
                                                         float* __restrict__ disp_r, int W, int H, int D, int dmin,
-                                                        int check_unique, float one_minus_ratio, int row0)
+                                                        int check_unique, float one_minus_ratio, int row0, int seg_len)
 {
     constexpr int Dp = 16 * DPL;
     constexpr int LD = Dp + 2;
@@ -930,16 +930,21 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
     }
     __syncthreads();
 
-    // main iterations cover the image columns; the right view then needs dmin + D - 1 more (virtual) columns:
-    // its last pixel W-1 completes with column W-1 + dmin + D-1
-    const int n_main = (W + COLS - 1) / COLS;
-    const int n_iter = do_right ? (W - 1 + dmin + D - 1) / COLS + 1 : n_main;
+    // A row may be cut into segments (blockIdx.z) so that a single frame still fills the GPU: the segment owns the
+    // left- and right-view pixels [xa, xb) and sums the columns they need, [xa, xb + dmin + D - 1) -- the overlap with
+    // the next segment is summed twice (never with SLOW: the host then uses one segment).
+    // Main iterations cover real columns; the right view of the last pixels may need (virtual) columns >= W.
+    const int xa = blockIdx.z * seg_len;
+    const int xb = min(W, xa + seg_len);
+    const int x_last = do_right ? xb - 1 + dmin + D - 1 : xb - 1;       // last column any pixel of the segment needs
+    const int n_main = (min(x_last + 1, W) - xa + COLS - 1) / COLS;
+    const int n_iter = (x_last - xa) / COLS + 1;
     const unsigned upper_mask = (ndirs > 4) ? 0xFFu : 0u;               // planes 4..7 count only with eight paths
 
     auto cell_off = [&](int x) { return row_cells + (size_t)min(x, W - 1) * Dp + sub * DPL; };
     CellVec<DPL> pre[2][8];
-    sumlr_prefetch<DPL, 0>(pre, planes, plane_bytes, ndirs, cell_off(px));
-    sumlr_prefetch<DPL, 1>(pre, planes, plane_bytes, ndirs, cell_off(COLS + px));
+    sumlr_prefetch<DPL, 0>(pre, planes, plane_bytes, ndirs, cell_off(xa + px));
+    sumlr_prefetch<DPL, 1>(pre, planes, plane_bytes, ndirs, cell_off(xa + COLS + px));
 
     int slot = px;                                                       // ring slot of this thread's column: x mod R
 
@@ -973,7 +978,7 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
         for (int i = 0; i < DPL; ++i) k2 = min(k2, key[i] + nbest);
         const unsigned ksecond = row_allmin<16>(k2) + kbest + 1;
         const int dbest = (int)(kbest & 0xFFFFu);
-        if (xr >= 0 && xr < W && sub == 0) {
+        if (xr >= xa && xr < xb && sub == 0) {
             // S[best-1], S[best+1] straight from the ring (a best at either end of the range is invalid anyway,
             // ref :428: clamp the index, the value is not used)
             const int km = max(dbest - 1, 0), kp = min(dbest + 1, Dp - 1);
@@ -997,8 +1002,9 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
 
     auto main_body = [&](int it, auto stage_tag) {
         constexpr int STAGE = decltype(stage_tag)::value;
-        const int x = it * COLS + px;
+        const int x = xa + it * COLS + px;
         const bool inside = x < W;
+        const bool mine = x < xb;                                        // left-view output (and S) of this segment
         const size_t off = cell_off(x);
         unsigned acc[DPL];
 #pragma unroll
@@ -1026,7 +1032,7 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
             }
         }
         if (SLOW) {
-            if (store_S && inside) {
+            if (store_S && mine) {
                 unsigned short* dst = S + off;
 #pragma unroll
                 for (int i = 0; i < DPL; i += 2)
@@ -1063,7 +1069,7 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
         const unsigned ksecond = row_allmin<16>(k2) + kbest + 1;
         const int dbest = (int)(kbest & 0xFFFFu);
         asm volatile("" ::: "memory");                                   // the wave's ring writes above stay above
-        if (inside && sub == 0) {
+        if (mine && sub == 0) {
             const int km = max(dbest - 1, 0), kp = min(dbest + 1, Dp - 1);
             WtaState st;
             st.m1 = kbest >> 16;
@@ -1092,7 +1098,7 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
         unsigned* dst = reinterpret_cast<unsigned*>(&ring[slot * LD + sub * DPL]);
 #pragma unroll
         for (int i = 0; i < DPL; i += 2) dst[i >> 1] = 0xFFFFFFFFu;
-        right_view(it * COLS + px);
+        right_view(xa + it * COLS + px);
         next_slot();
     }
 }
@@ -1668,13 +1674,13 @@ template <int DPL, int THREADS>
 static void launch_sum_wta_lr(dim3 grid, hipStream_t st, const void* planes, size_t plane_bytes, int ndirs, const void* extras,
                               const void* row_extras, const void* row_extra_count, int row_cap, int accumulate, int store_S,
                               int do_right, void* S, void* disp_l, void* disp_r, const sgmd_geom* g, int check_unique,
-                              float one_minus_ratio)
+                              float one_minus_ratio, int seg_len)
 {
 #define SUMLR_CALL(SLOW)                                                                                              \
     hipLaunchKernelGGL((sgm_sum_wta_lr_k<DPL, SLOW, THREADS>), grid, dim3(THREADS), 0, st, (const uint8_t*)planes, plane_bytes, ndirs, \
                        (const uint8_t*)extras, (const sgmd_row_extra*)row_extras, (const int*)row_extra_count, row_cap,  \
                        accumulate, store_S, do_right, (uint16_t*)S, (float*)disp_l, (float*)disp_r, g->W, g->H, g->D,    \
-                       g->dmin, check_unique, one_minus_ratio, g->row_begin)
+                       g->dmin, check_unique, one_minus_ratio, g->row_begin, seg_len)
     if (accumulate || store_S) SUMLR_CALL(true);
     else SUMLR_CALL(false);
 #undef SUMLR_CALL
@@ -1930,9 +1936,22 @@ int sgmd_sum_wta_lr(int ord, void* stream, const sgmd_geom* g, int ndirs, const 
                     int store_S, int do_right, void* S, int check_unique, float one_minus_ratio, void* disp_l, void* disp_r)
 {
     HIP_TRY(hipSetDevice(ord));
-    const dim3 grid(g->row_end - g->row_begin, g->B);
+    // segments per row: enough workgroups for ~4 per CU when a launch has few rows (one frame), but never segments
+    // shorter than 2 Dp columns (each re-sums dmin + D - 1 columns of its right neighbour), and one segment whenever S
+    // is read or written (the overlap would be accumulated twice)
+    const int rows = (g->row_end - g->row_begin) * g->B;
+    int segs = 1;
+    if (!accumulate && !store_S) {
+        const char* e = getenv("SGM_SUM_SEGMENTS");
+        segs = (e && *e) ? atoi(e) : (1024 + rows - 1) / rows;
+        if (segs > 4) segs = 4;
+        while (segs > 1 && g->W / segs < 2 * g->Dp) --segs;
+        if (segs < 1) segs = 1;
+    }
+    const int seg_len = (((g->W + segs - 1) / segs) + 15) / 16 * 16;
+    const dim3 grid(g->row_end - g->row_begin, g->B, (g->W + seg_len - 1) / seg_len);
     hipStream_t st = (hipStream_t)stream;
-#define SUMLR_ARGS grid, st, planes, plane_bytes, ndirs, extras, row_extras, row_extra_count, row_cap, accumulate, store_S, do_right, S, disp_l, disp_r, g, check_unique, one_minus_ratio
+#define SUMLR_ARGS grid, st, planes, plane_bytes, ndirs, extras, row_extras, row_extra_count, row_cap, accumulate, store_S, do_right, S, disp_l, disp_r, g, check_unique, one_minus_ratio, seg_len
     switch (g->Dp / 16) {
     case 2: launch_sum_wta_lr<2, 256>(SUMLR_ARGS); break;
     case 4: launch_sum_wta_lr<4, 256>(SUMLR_ARGS); break;

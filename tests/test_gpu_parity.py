@@ -28,15 +28,15 @@ def assert_same(got, want, what):
                              f"gpu={got[first]} oracle={want[first]}")
 
 
-@pytest.fixture(scope="module", params=["auto", "fused"])
+@pytest.fixture(scope="module", params=["fused", "separate"])
 def inst(request):
-    """Every test on this instance runs twice: with the library's own choice between the two cost-sum/WTA paths
-    (separate kernels for launches of < 1024 image rows) and with the fused row kernel forced where it exists
-    (Dp <= 128; SGM_FUSED_WTA is read at SGM_Initialize / SGM_Reset)."""
+    """Every test on this instance runs twice: with the library's default cost-sum/WTA path (the fused row kernel
+    where it exists, Dp <= 128) and with the separate sum / right-view kernels forced (what D > 128 always uses;
+    SGM_FUSED_WTA is read at SGM_Initialize / SGM_Reset)."""
     import os
     import soc_project_stereo_matching_amd as S
-    if request.param == "fused":
-        os.environ["SGM_FUSED_WTA"] = "1"
+    if request.param == "separate":
+        os.environ["SGM_FUSED_WTA"] = "0"
     i = S.SGMInstance(0)
     i.keep_stages(True)
     yield i
@@ -225,6 +225,30 @@ def test_lane_layouts_of_the_aggregation_kernel(oracle, hl, lanes, monkeypatch):
             out = i.match(left, right)
             assert_same(i.read_stage("aggr"), want["aggr"], f"S {w}x{h} d{dmin}-{dmax} HL={hl} lanes={lanes}")
             assert_same(out, want["final"], f"final {w}x{h} d{dmin}-{dmax} HL={hl} lanes={lanes}")
+    finally:
+        i.close()
+
+
+@pytest.mark.parametrize("segments", ["1", "2", "3", "4"])
+def test_row_segments_of_the_fused_sum_kernel(oracle, segments, monkeypatch):
+    """The fused cost-sum/WTA kernel cuts rows into segments when a launch has few rows; segments overlap by
+    dmin + D - 1 columns (re-summed) and must not change either disparity view."""
+    import soc_project_stereo_matching_amd as S
+    from oracle.pyoracle import default_option
+    monkeypatch.setenv("SGM_SUM_SEGMENTS", segments)
+    monkeypatch.setenv("SGM_FUSED_WTA", "1")
+    i = S.SGMInstance(0)
+    i.keep_stages(False)                       # S not stored: segments are only used then
+    try:
+        for (w, h, dmin, dmax) in [(1242, 24, 0, 128), (530, 20, 5, 98), (300, 17, 0, 64), (257, 9, 2, 30), (2000, 6, 0, 128)]:
+            left, right = oracle.synth_pair(w, h, dmax - dmin, 0x5E6 + w)
+            opt = default_option(dmax, dmin, min_speckle_area=10)
+            want = oracle.run(left, right, opt)
+            assert i.reset(w, h, opt)
+            out = i.match(left, right)
+            assert_same(i.read_stage("disp_r"), want["disp_r"], f"right view {w}x{h} d{dmin}-{dmax} segments={segments}")
+            assert_same(out, want["final"], f"final {w}x{h} d{dmin}-{dmax} segments={segments}")
+            assert_same(i.read_stage("aggr"), want["aggr"], f"S (materialised afterwards) {w}x{h}")
     finally:
         i.close()
 
