@@ -93,7 +93,7 @@ int sgmd_sum_wta(int ord, void* stream, const sgmd_geom* g, int ndirs, const voi
                  const void* extras, const void* row_extras, const void* row_extra_count, int row_cap, int accumulate,
                  void* S, int check_unique, float one_minus_ratio, void* disp_l);
 
-/* The same sum and BOTH winner-take-all passes in one kernel (Dp <= 128: sgmd_sum_wta_lr_supported): a workgroup
+/* The same sum and BOTH winner-take-all passes in one kernel (Dp <= 256: sgmd_sum_wta_lr_supported): a workgroup
  * walks an image row and keeps the last Dp+32 columns of S in LDS for the right view's diagonal gather, so S is
  * written only if store_S (and read only if accumulate); do_right = 0 skips the right view (no LR check). */
 int sgmd_sum_wta_lr_supported(const sgmd_geom* g, int row_cap);   /* row_cap: most anomalous-line visits in one row */

@@ -43,7 +43,7 @@ struct sgm_instance {
 
     bool initialized;
     bool s_is_zero;              /* aggregated-cost volume logically zero (set by Initialize/Reset, Q14) */
-    int fused_wta;               /* Dp <= 128: cost sum and both WTA passes in one kernel, S not written */
+    int fused_wta;               /* Dp <= 256: cost sum and both WTA passes in one kernel, S not written */
     bool s_pending;              /* the planes hold a frame whose sum has not been put into d_S (fused kernel, S not
                                     stored): done lazily when somebody needs S -- a Match without Reset, a stage read */
     bool s_pending_accumulate;   /* ... and that sum adds to d_S (true) or replaces it */

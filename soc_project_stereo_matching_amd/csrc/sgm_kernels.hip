@@ -865,7 +865,7 @@ __global__ __launch_bounds__(256) void sgm_sum_wta_k(const uint8_t* __restrict__
 }
 
 // ============================================================================================
-// Fused cost sum + BOTH winner-take-all passes (Dp <= 128): one workgroup walks one image row, 16 columns per
+// Fused cost sum + BOTH winner-take-all passes (Dp <= 256): one workgroup walks one image row, 16 columns per
 // iteration (16 lanes per pixel as in sgm_sum_wta_k).  The S vectors of the last Dp+32 columns stay in an LDS
 // ring, so the right view -- cost of right pixel xr at disparity d is S[y][xr+d][d-dmin] (ref :397-408), a
 // diagonal through Dp consecutive columns -- is evaluated from LDS as soon as its last column has been summed,
@@ -1928,7 +1928,7 @@ int sgmd_sum_wta(int ord, void* stream, const sgmd_geom* g, int ndirs, const voi
 
 int sgmd_sum_wta_lr_supported(const sgmd_geom* g, int row_cap)
 {
-    return (g->Dp == 32 || g->Dp == 64 || g->Dp == 128) && row_cap <= SUMLR_MAX_EXTRA;
+    return (g->Dp == 32 || g->Dp == 64 || g->Dp == 128 || g->Dp == 192 || g->Dp == 256) && row_cap <= SUMLR_MAX_EXTRA;
 }
 
 int sgmd_sum_wta_lr(int ord, void* stream, const sgmd_geom* g, int ndirs, const void* planes, size_t plane_bytes,
@@ -1956,8 +1956,11 @@ int sgmd_sum_wta_lr(int ord, void* stream, const sgmd_geom* g, int ndirs, const 
     case 2: launch_sum_wta_lr<2, 256>(SUMLR_ARGS); break;
     case 4: launch_sum_wta_lr<4, 256>(SUMLR_ARGS); break;
     case 8: launch_sum_wta_lr<8, 256>(SUMLR_ARGS); break;   // (512 threads = 32 columns per iteration measured the same)
+    // larger ranges: the ring takes most of the CU's 160 KB of LDS, one workgroup per CU
+    case 12: launch_sum_wta_lr<12, 512>(SUMLR_ARGS); break;  // Dp 192: ring 256 x 194 u16 =  97 KB, 8 waves
+    case 16: launch_sum_wta_lr<16, 256>(SUMLR_ARGS); break;  // Dp 256: ring 288 x 258 u16 = 145 KB, 4 waves
     default:
-        fprintf(stderr, "sgm_mi355x: fused sum/WTA needs Dp <= 128 (got %d)\n", g->Dp);
+        fprintf(stderr, "sgm_mi355x: fused sum/WTA needs Dp <= 256 (got %d)\n", g->Dp);
         return -1;
     }
 #undef SUMLR_ARGS

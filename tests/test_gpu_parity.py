@@ -31,7 +31,7 @@ def assert_same(got, want, what):
 @pytest.fixture(scope="module", params=["fused", "separate"])
 def inst(request):
     """Every test on this instance runs twice: with the library's default cost-sum/WTA path (the fused row kernel
-    where it exists, Dp <= 128) and with the separate sum / right-view kernels forced (what D > 128 always uses;
+    where it exists, Dp <= 256) and with the separate sum / right-view kernels forced (what D > 256 always uses;
     SGM_FUSED_WTA is read at SGM_Initialize / SGM_Reset)."""
     import os
     import soc_project_stereo_matching_amd as S
@@ -217,7 +217,8 @@ def test_lane_layouts_of_the_aggregation_kernel(oracle, hl, lanes, monkeypatch):
     monkeypatch.setenv("SGM_LANES_PER_PIXEL", lanes)
     i = S.SGMInstance(0)
     try:
-        for (w, h, dmin, dmax) in [(300, 40, 0, 128), (200, 30, 0, 256), (150, 25, 3, 93), (90, 33, 0, 64), (70, 20, 0, 512)]:
+        for (w, h, dmin, dmax) in [(300, 40, 0, 128), (200, 30, 0, 256), (150, 25, 3, 93), (90, 33, 0, 64), (70, 20, 0, 512),
+                                   (260, 22, 0, 192), (420, 18, 4, 180)]:
             left, right = oracle.synth_pair(w, h, dmax - dmin, 0x1A7E5 + w)
             opt = default_option(dmax, dmin, min_speckle_area=10)
             want = oracle.run(left, right, opt)
@@ -240,7 +241,8 @@ def test_row_segments_of_the_fused_sum_kernel(oracle, segments, monkeypatch):
     i = S.SGMInstance(0)
     i.keep_stages(False)                       # S not stored: segments are only used then
     try:
-        for (w, h, dmin, dmax) in [(1242, 24, 0, 128), (530, 20, 5, 98), (300, 17, 0, 64), (257, 9, 2, 30), (2000, 6, 0, 128)]:
+        for (w, h, dmin, dmax) in [(1242, 24, 0, 128), (530, 20, 5, 98), (300, 17, 0, 64), (257, 9, 2, 30), (2000, 6, 0, 128),
+                                   (1100, 8, 0, 192), (1300, 7, 3, 250)]:
             left, right = oracle.synth_pair(w, h, dmax - dmin, 0x5E6 + w)
             opt = default_option(dmax, dmin, min_speckle_area=10)
             want = oracle.run(left, right, opt)
