@@ -1,0 +1,95 @@
+#include "sgm_common.hpp"
+
+// ============================================================================================
+// census 5x5  (ref :134-159)
+// ============================================================================================
+
+__global__ __launch_bounds__(256) void sgm_census_k(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
+                                                    uint32_t* __restrict__ cl, uint32_t* __restrict__ cr, int W, int H)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const size_t frame_px = (size_t)(blockIdx.z >> 1) * W * H;         // batch: z = 2 * frame + image
+    const uint8_t* img = ((blockIdx.z & 1) ? right : left) + frame_px;
+    uint32_t* out = ((blockIdx.z & 1) ? cr : cl) + frame_px;
+    uint32_t bits = 0;
+    // border of 2 px is never written by the reference (zero-initialised statics, Q3); also nothing
+    // at all is written for images with W <= 5 or H <= 5 (ref :136)
+    if (W > 5 && H > 5 && x >= 2 && x < W - 2 && y >= 2 && y < H - 2) {
+        const unsigned centre = img[(size_t)y * W + x];
+#pragma unroll
+        for (int r = -2; r <= 2; ++r)
+#pragma unroll
+            for (int c = -2; c <= 2; ++c) bits = (bits << 1) | (unsigned)(img[(size_t)(y + r) * W + (x + c)] < centre);
+    }
+    out[(size_t)y * W + x] = bits;
+}
+
+// ============================================================================================
+// matching cost  (ref :161-196): one thread = 16 consecutive disparities of one pixel
+// ============================================================================================
+
+__global__ __launch_bounds__(256) void sgm_cost_k(const uint32_t* __restrict__ cl, const uint32_t* __restrict__ cr,
+                                                  uint8_t* __restrict__ cost, int W, int H, int D, int Dp, int dmin)
+{
+    const int chunks = Dp >> 4;                       // Dp is a multiple of 32
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)W * H * chunks;
+    if (t >= total) return;
+    cl += (size_t)blockIdx.y * W * H;                                  // batch: y = frame
+    cr += (size_t)blockIdx.y * W * H;
+    cost += (size_t)blockIdx.y * W * H * Dp;
+    const int chunk = (int)(t % chunks);
+    const long long pix = t / chunks;
+    const int x = (int)(pix % W);
+    const uint32_t a = cl[pix];
+    const uint32_t* rrow = cr + (pix - x);
+    unsigned w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned word = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int di = chunk * 16 + q * 4 + b;    // index into the volume
+            const int xr = x - (dmin + di);
+            unsigned c = 127u;                        // off-image: UINT8_MAX/2 (ref :170-171)
+            if (di < D && xr >= 0 && xr < W) c = (unsigned)__popc(a ^ rrow[xr]);
+            word |= c << (8 * b);
+        }
+        w[q] = word;
+    }
+    *reinterpret_cast<uint4*>(cost + pix * Dp + chunk * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+
+extern "C" {
+
+size_t sgmd_census_slack(const sgmd_geom* g)
+{
+    // lowest census-right index read is p - (dmin + Dp - 1) with p >= 0; round up to 256 B
+    return (((size_t)g->dmin + g->Dp + 8) * sizeof(uint32_t) + 255) & ~(size_t)255;
+}
+
+int sgmd_census(int ord, void* stream, const sgmd_geom* g, const void* left, const void* right, void* cl, void* cr)
+{
+    HIP_TRY(hipSetDevice(ord));
+    dim3 grid((g->W + 63) / 64, (g->H + 3) / 4, 2 * g->B);
+    hipLaunchKernelGGL(sgm_census_k, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)left,
+                       (const uint8_t*)right, (uint32_t*)cl, (uint32_t*)cr, g->W, g->H);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sgmd_cost(int ord, void* stream, const sgmd_geom* g, const void* cl, const void* cr, void* cost)
+{
+    HIP_TRY(hipSetDevice(ord));
+    const long long total = (long long)g->W * g->H * (g->Dp / 16);
+    dim3 grid((unsigned)((total + 255) / 256), g->B);
+    hipLaunchKernelGGL(sgm_cost_k, grid, dim3(256), 0, (hipStream_t)stream, (const uint32_t*)cl, (const uint32_t*)cr,
+                       (uint8_t*)cost, g->W, g->H, g->D, g->Dp, g->dmin);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -1,6 +1,6 @@
 /*
  * sgm_device.h -- the thin C interface between the C host (sgm_host.c) and the HIP translation
- * unit (sgm_kernels.hip).  Plain C types only; device memory is passed as void*.
+ * units (sgm_*.hip).  Plain C types only; device memory is passed as void*.
  * Every function returns 0 on success and a non-zero HIP error code otherwise (the message is
  * printed to stderr by the HIP side), except where noted.
  */

@@ -1,0 +1,130 @@
+#include "sgm_common.hpp"
+
+// device, stream, memory and event-timer helpers behind sgm_device.h
+
+extern "C" {
+
+int sgmd_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int sgmd_device_is_gfx950(int ordinal)
+{
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ordinal) != hipSuccess) return -1;
+    return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+int sgmd_stream_create(int ord, void** stream)
+{
+    HIP_TRY(hipSetDevice(ord));
+    hipStream_t s;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void*)s;
+    return 0;
+}
+int sgmd_stream_destroy(int ord, void* stream)
+{
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+}
+int sgmd_stream_sync(int ord, void* stream)
+{
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+int sgmd_alloc(int ord, void** dptr, size_t bytes)
+{
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 16));
+    return 0;
+}
+int sgmd_free(int ord, void* dptr)
+{
+    if (!dptr) return 0;
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipFree(dptr));
+    return 0;
+}
+int sgmd_alloc_pinned(int ord, void** hptr, size_t bytes)
+{
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipHostMalloc(hptr, bytes ? bytes : 16, hipHostMallocDefault));
+    return 0;
+}
+int sgmd_free_pinned(int ord, void* hptr)
+{
+    if (!hptr) return 0;
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipHostFree(hptr));
+    return 0;
+}
+int sgmd_h2d_async(int ord, void* stream, void* dst, const void* src, size_t bytes)
+{
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return 0;
+}
+int sgmd_d2h_async(int ord, void* stream, void* dst, const void* src, size_t bytes)
+{
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return 0;
+}
+int sgmd_d2d_async(int ord, void* stream, void* dst, const void* src, size_t bytes)
+{
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+int sgmd_memset_async(int ord, void* stream, void* dst, int value, size_t bytes)
+{
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
+    return 0;
+}
+
+struct sgmd_timer { int n; hipEvent_t* ev; };
+
+int sgmd_timer_create(int ord, void** timer, int max_marks)
+{
+    HIP_TRY(hipSetDevice(ord));
+    sgmd_timer* t = new sgmd_timer;
+    t->n = max_marks;
+    t->ev = new hipEvent_t[max_marks];
+    for (int i = 0; i < max_marks; ++i) HIP_TRY(hipEventCreate(&t->ev[i]));
+    *timer = t;
+    return 0;
+}
+void sgmd_timer_destroy(int ord, void* timer)
+{
+    if (!timer) return;
+    (void)hipSetDevice(ord);
+    sgmd_timer* t = (sgmd_timer*)timer;
+    for (int i = 0; i < t->n; ++i) (void)hipEventDestroy(t->ev[i]);
+    delete[] t->ev;
+    delete t;
+}
+int sgmd_timer_mark(int ord, void* timer, void* stream, int index)
+{
+    sgmd_timer* t = (sgmd_timer*)timer;
+    if (!t || index < 0 || index >= t->n) return -1;
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipEventRecord(t->ev[index], (hipStream_t)stream));
+    return 0;
+}
+int sgmd_timer_elapsed(int ord, void* timer, int from, int to, float* ms)
+{
+    sgmd_timer* t = (sgmd_timer*)timer;
+    if (!t) return -1;
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipEventElapsedTime(ms, t->ev[from], t->ev[to]));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,539 @@
+#include "sgm_common.hpp"
+
+
+// S = [S +] sum of the L_r planes (+ second visits of the anomalous lines), and -- while the 16 lanes of a
+// pixel still hold its S vector in registers -- the LEFT-view winner-take-all (ref :374-443 with
+// inverse == 0).  16 lanes per pixel, DPL disparities per lane; the kernel is HBM-bound (it streams the 8
+// planes once), so the WTA arithmetic rides along for free.
+//   key = S << 16 | d: the row-wide minimum key is the first minimum the reference's strict '>' finds.
+template <int DPL>
+__global__ __launch_bounds__(256) void sgm_sum_wta_k(const uint8_t* __restrict__ planes, size_t plane_bytes, int ndirs,
+                                                     const uint8_t* __restrict__ extras,
+                                                     const sgmd_row_extra* __restrict__ row_extras,
+                                                     const int* __restrict__ row_extra_count, int row_cap, int accumulate,
+                                                     uint16_t* __restrict__ S, float* __restrict__ disp_l, int W, int H, int D,
+                                                     int Dp, int dmin, int check_unique, float one_minus_ratio, int row0)
+{
+    const int sub = threadIdx.x & 15;
+    const int xr = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool inside = xr < W;
+    const int x = inside ? xr : W - 1;                                  // keep the DPP rows converged; stores are masked
+    const int row = row0 + blockIdx.y;                                  // row0: first row of this GPU's row tile
+    const size_t off = ((size_t)row * W + x) * Dp + sub * DPL;
+    planes += (size_t)blockIdx.z * 8 * plane_bytes;                     // batch: z = frame
+    extras += (size_t)blockIdx.z * 4 * H * Dp;
+    S += (size_t)blockIdx.z * W * H * Dp;
+    disp_l += (size_t)blockIdx.z * W * H;
+
+    unsigned acc[DPL];
+    if (accumulate) {                                    // Q14: S was not reset since the last frame
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) acc[i] = S[off + i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) acc[i] = 0;
+    }
+    auto add_cells = [&](const uint8_t* p, bool nt) {
+        CellVec<DPL> v;
+        if (nt) load_cells_nt<DPL>(p, v); else load_cells<DPL>(p, v);
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) acc[i] += (v.w[i >> 2] >> (8 * (i & 3))) & 0xFF;
+    };
+    for (int d = 0; d < ndirs; ++d) add_cells(planes + (size_t)d * plane_bytes + off, true);
+    if (ndirs > 4) {
+        const int n = row_extra_count[row];
+        for (int j = 0; j < n; ++j) {
+            const sgmd_row_extra e = row_extras[row * row_cap + j];
+            if ((e.col_slot & 0xFFFF) == x)
+                add_cells(extras + ((size_t)(e.col_slot >> 16) * H + e.step) * Dp + sub * DPL, false);
+        }
+    }
+    if (inside) {
+        unsigned short* dst = S + off;
+#pragma unroll
+        for (int i = 0; i < DPL; i += 2)
+            *reinterpret_cast<unsigned*>(dst + i) = (acc[i] & 0xFFFFu) | (acc[i + 1] << 16);
+    }
+
+    // ---- left-view WTA over the 16 lanes of the pixel ----
+    unsigned key[DPL];
+    unsigned kmin = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+        const int idx = sub * DPL + i;
+        key[i] = (idx < D) ? (((acc[i] & 0xFFFFu) << 16) | (unsigned)idx) : 0xFFFFFFFFu;
+        kmin = min(kmin, key[i]);
+    }
+    const unsigned kbest = row_allmin<16>(kmin);
+    unsigned k2 = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) k2 = min(k2, key[i] == kbest ? 0xFFFFFFFFu : key[i]);
+    const unsigned ksecond = row_allmin<16>(k2);
+    const int dbest = (int)(kbest & 0xFFFFu);
+    unsigned nb = 0;                                     // S[best-1] | S[best+1] << 16 (ref :432-435)
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) {
+        const int idx = sub * DPL + i;
+        if (idx == dbest - 1) nb |= acc[i] & 0xFFFFu;
+        if (idx == dbest + 1) nb |= acc[i] << 16;
+    }
+    nb = row_allor(nb);
+    if (inside && sub == 0) {
+        WtaState st;
+        st.m1 = kbest >> 16;
+        st.m2 = ksecond >> 16;                           // 0xFFFF if there is no other disparity, as ref :381
+        st.d1 = (kbest == 0xFFFFFFFFu) ? -1 : dbest;
+        st.c1 = nb & 0xFFFFu;
+        st.c2 = nb >> 16;
+        st.pv = 0; st.want_next = false;
+        disp_l[(size_t)row * W + x] = wta_finish(st, D, dmin, check_unique, one_minus_ratio);
+    }
+}
+
+// ============================================================================================
+// Fused cost sum + BOTH winner-take-all passes (Dp <= 256): one workgroup walks one image row, 16 columns per
+// iteration (16 lanes per pixel as in sgm_sum_wta_k).  The S vectors of the last Dp+32 columns stay in an LDS
+// ring, so the right view -- cost of right pixel xr at disparity d is S[y][xr+d][d-dmin] (ref :397-408), a
+// diagonal through Dp consecutive columns -- is evaluated from LDS as soon as its last column has been summed,
+// with the same 16-lane key-min reduction as the left view.  S itself is then needed by nobody: it is written
+// only on request (stage read-back; the host materialises it lazily for a Match without Reset, Q14).  Per
+// frame that removes the S write (119 MB at KITTI size) and the S read of sgm_wta_right_k (143 MB) of 1.37 GB.
+//   ring: u16 [R][LD], R = Dp + 32 columns, LD = Dp + 2 (odd dword stride); entries of columns >= W and of
+//   padding disparities hold 65535 = the reference's "off the image" cost (ref :407).
+// ============================================================================================
+template <int DPL, int STAGE>
+static __device__ __forceinline__ void sumlr_prefetch(CellVec<DPL> (&pre)[2][8], const uint8_t* planes, size_t plane_bytes,
+                                                      int ndirs, size_t off)
+{
+    // always 8 unconditional loads (see SLOW below): with four paths the upper four re-read planes 0..3 and are
+    // masked out when they are added
+#pragma unroll
+    for (int d = 0; d < 8; ++d)
+        load_cells_nt<DPL>(planes + (size_t)(d < ndirs ? d : d - 4) * plane_bytes + off, pre[STAGE][d]);
+}
+
+// SLOW = the variant that may read (accumulate) or write (store_S) S.  The common one has no conditional global
+// access inside the loop at all: hipcc merges s_waitcnt counts over all control-flow paths, and a load behind a
+// condition or in a loop of unknown trip count makes it drain the two-iterations-deep plane prefetch (vmcnt(0))
+// every iteration -- which is why columns past the row end re-read the last column instead of being skipped, why
+// the right-view-only iterations after the last column are a loop of their own, and why the anomalous-line
+// visits of the row are staged in LDS up front.
+#define SUMLR_MAX_EXTRA 8
+template <int DPL, bool SLOW, int THREADS>
+__global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __restrict__ planes, size_t plane_bytes, int ndirs,
+                                                        const uint8_t* __restrict__ extras,
+                                                        const sgmd_row_extra* __restrict__ row_extras,
+                                                        const int* __restrict__ row_extra_count, int row_cap,
+                                                        int accumulate, int store_S, int do_right,
+                                                        uint16_t* __restrict__ S, float* __restrict__ disp_l,
+                                                        float* __restrict__ disp_r, int W, int H, int D, int dmin,
+                                                        int check_unique, float one_minus_ratio, int row0, int seg_len)
+{
+    constexpr int Dp = 16 * DPL;
+    constexpr int LD = Dp + 2;
+    constexpr int COLS = THREADS / 16;                                   // columns per iteration
+    constexpr int R = Dp + 2 * COLS;
+    static_assert(R % COLS == 0, "a ring slot must always belong to the same px");
+    __shared__ unsigned short ring[R * LD];
+    __shared__ unsigned ex_val[SUMLR_MAX_EXTRA * (Dp / 4)];
+    __shared__ int ex_col[SUMLR_MAX_EXTRA];
+
+    const int sub = threadIdx.x & 15;
+    const int px = threadIdx.x >> 4;
+    const int row = row0 + blockIdx.x;
+    planes += (size_t)blockIdx.y * 8 * plane_bytes;                     // batch: y = frame
+    extras += (size_t)blockIdx.y * 4 * H * Dp;
+    S += (size_t)blockIdx.y * W * H * Dp;
+    disp_l += (size_t)blockIdx.y * W * H;
+    disp_r += (size_t)blockIdx.y * W * H;
+    const size_t row_cells = (size_t)row * W * Dp;
+    const int n_extra = (ndirs > 4) ? min(row_extra_count[row], SUMLR_MAX_EXTRA) : 0;    // host: row_cap <= SUMLR_MAX_EXTRA
+    for (int t = threadIdx.x; t < n_extra * (Dp / 4); t += THREADS) {
+        const int j = t / (Dp / 4), w = t % (Dp / 4);
+        const sgmd_row_extra e = row_extras[row * row_cap + j];
+        if (w == 0) ex_col[j] = e.col_slot & 0xFFFF;
+        ex_val[t] = *reinterpret_cast<const unsigned*>(extras + ((size_t)(e.col_slot >> 16) * H + e.step) * Dp + w * 4);
+    }
+    __syncthreads();
+
+    // A row may be cut into segments (blockIdx.z) so that a single frame still fills the GPU: the segment owns the
+    // left- and right-view pixels [xa, xb) and sums the columns they need, [xa, xb + dmin + D - 1) -- the overlap with
+    // the next segment is summed twice (never with SLOW: the host then uses one segment).
+    // Main iterations cover real columns; the right view of the last pixels may need (virtual) columns >= W.
+    const int xa = blockIdx.z * seg_len;
+    const int xb = min(W, xa + seg_len);
+    const int x_last = do_right ? xb - 1 + dmin + D - 1 : xb - 1;       // last column any pixel of the segment needs
+    const int n_main = (min(x_last + 1, W) - xa + COLS - 1) / COLS;
+    const int n_iter = (x_last - xa) / COLS + 1;
+    const unsigned upper_mask = (ndirs > 4) ? 0xFFu : 0u;               // planes 4..7 count only with eight paths
+
+    auto cell_off = [&](int x) { return row_cells + (size_t)min(x, W - 1) * Dp + sub * DPL; };
+    CellVec<DPL> pre[2][8];
+    sumlr_prefetch<DPL, 0>(pre, planes, plane_bytes, ndirs, cell_off(xa + px));
+    sumlr_prefetch<DPL, 1>(pre, planes, plane_bytes, ndirs, cell_off(xa + COLS + px));
+
+    int slot = px;                                                       // ring slot of this thread's column: x mod R
+
+    // right-view WTA of the pixel whose last column (disparity D-1) is column x, after the ring holds column x
+    auto right_view = [&](int x) {
+        __syncthreads();                                                 // the new columns are in the ring
+        const int xr = x - dmin - (D - 1);
+        int base = slot + R - (D - 1);                                   // ring slot of column xr + dmin = x - (D-1)
+        if (base >= R) base -= R;
+        unsigned key[DPL], val[DPL];
+        unsigned kmin = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) {
+            const int k = sub * DPL + i;
+            int sl = base + k;
+            if (sl >= R) sl -= R;
+            val[i] = ring[sl * LD + k];                                  // padding disparities hold 65535
+        }
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) {
+            const int k = sub * DPL + i;
+            key[i] = (k < D) ? ((val[i] << 16) | (unsigned)k) : 0xFFFFFFFFu;
+            kmin = min(kmin, key[i]);
+        }
+        const unsigned kbest = row_allmin<16>(kmin);
+        // runner-up: keys are distinct (they carry d), so key - kbest - 1 (mod 2^32) sends the best to the top
+        // and keeps the order of all others
+        const unsigned nbest = ~kbest;
+        unsigned k2 = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) k2 = min(k2, key[i] + nbest);
+        const unsigned ksecond = row_allmin<16>(k2) + kbest + 1;
+        const int dbest = (int)(kbest & 0xFFFFu);
+        if (xr >= xa && xr < xb && sub == 0) {
+            // S[best-1], S[best+1] straight from the ring (a best at either end of the range is invalid anyway,
+            // ref :428: clamp the index, the value is not used)
+            const int km = max(dbest - 1, 0), kp = min(dbest + 1, Dp - 1);
+            int sm = base + km, sp = base + kp;
+            if (sm >= R) sm -= R;
+            if (sp >= R) sp -= R;
+            WtaState st;
+            st.m1 = kbest >> 16;
+            st.m2 = ksecond >> 16;
+            st.d1 = ((kbest >> 16) == 0xFFFFu) ? -1 : dbest;             // nothing beat 65535 (ref :381, strict '>')
+            st.c1 = ring[sm * LD + km];
+            st.c2 = ring[sp * LD + kp];
+            st.pv = 0; st.want_next = false;
+            disp_r[(size_t)row * W + xr] = wta_finish(st, D, dmin, check_unique, one_minus_ratio);
+        }
+    };
+    auto next_slot = [&]() {
+        slot += COLS;
+        if (slot >= R) slot -= R;
+    };
+
+    auto main_body = [&](int it, auto stage_tag) {
+        constexpr int STAGE = decltype(stage_tag)::value;
+        const int x = xa + it * COLS + px;
+        const bool inside = x < W;
+        const bool mine = x < xb;                                        // left-view output (and S) of this segment
+        const size_t off = cell_off(x);
+        unsigned acc[DPL];
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) acc[i] = 0;
+        if (SLOW) {
+            if (accumulate) {                                            // Q14: S was not reset since the last frame
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) acc[i] = S[off + i];
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const unsigned m = (d < 4) ? 0xFFu : upper_mask;
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) acc[i] += (pre[STAGE][d].w[i >> 2] >> (8 * (i & 3))) & m;
+        }
+        sumlr_prefetch<DPL, STAGE>(pre, planes, plane_bytes, ndirs, cell_off(x + 2 * COLS));     // columns of iteration it + 2
+        for (int j = 0; j < n_extra; ++j) {
+            if (ex_col[j] == x) {                                        // second visit of an anomalous line (LDS)
+#pragma unroll
+                for (int i = 0; i < DPL; ++i) {
+                    const int b = sub * DPL + i;
+                    acc[i] += (ex_val[j * (Dp / 4) + (b >> 2)] >> (8 * (b & 3))) & 0xFF;
+                }
+            }
+        }
+        if (SLOW) {
+            if (store_S && mine) {
+                unsigned short* dst = S + off;
+#pragma unroll
+                for (int i = 0; i < DPL; i += 2)
+                    *reinterpret_cast<unsigned*>(dst + i) = (acc[i] & 0xFFFFu) | (acc[i + 1] << 16);
+            }
+        }
+        // ---- this column's S vector into the ring (65535 outside the image / the disparity range) ----
+        // (also without a right view: the left view fetches S[best +- 1] from here.  A column's slot is only ever
+        // written by the wave that owns px = slot mod 16 -- R is a multiple of 16 -- so that read-back needs no barrier)
+        {
+            unsigned* dst = reinterpret_cast<unsigned*>(&ring[slot * LD + sub * DPL]);
+#pragma unroll
+            for (int i = 0; i < DPL; i += 2) {
+                const int idx = sub * DPL + i;
+                const unsigned lo = (inside && idx < D) ? (acc[i] & 0xFFFFu) : 0xFFFFu;
+                const unsigned hi = (inside && idx + 1 < D) ? (acc[i + 1] & 0xFFFFu) : 0xFFFFu;
+                dst[i >> 1] = lo | (hi << 16);
+            }
+        }
+        // ---- left-view WTA over the 16 lanes of the pixel (as in sgm_sum_wta_k) ----
+        unsigned key[DPL];
+        unsigned kmin = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) {
+            const int idx = sub * DPL + i;
+            key[i] = (idx < D) ? (((acc[i] & 0xFFFFu) << 16) | (unsigned)idx) : 0xFFFFFFFFu;
+            kmin = min(kmin, key[i]);
+        }
+        const unsigned kbest = row_allmin<16>(kmin);
+        const unsigned nbest = ~kbest;                                   // runner-up as in right_view()
+        unsigned k2 = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) k2 = min(k2, key[i] + nbest);
+        const unsigned ksecond = row_allmin<16>(k2) + kbest + 1;
+        const int dbest = (int)(kbest & 0xFFFFu);
+        asm volatile("" ::: "memory");                                   // the wave's ring writes above stay above
+        if (mine && sub == 0) {
+            const int km = max(dbest - 1, 0), kp = min(dbest + 1, Dp - 1);
+            WtaState st;
+            st.m1 = kbest >> 16;
+            st.m2 = ksecond >> 16;
+            st.d1 = (kbest == 0xFFFFFFFFu) ? -1 : dbest;
+            st.c1 = ring[slot * LD + km];                                // S[best-1], S[best+1] (unused when best is at an end)
+            st.c2 = ring[slot * LD + kp];
+            st.pv = 0; st.want_next = false;
+            disp_l[(size_t)row * W + x] = wta_finish(st, D, dmin, check_unique, one_minus_ratio);
+        }
+        if (do_right) right_view(x);
+        next_slot();
+    };
+
+    int it = 0;
+    for (; it + 1 < n_main; it += 2) {
+        main_body(it, std::integral_constant<int, 0>{});
+        main_body(it + 1, std::integral_constant<int, 1>{});
+    }
+    if (it < n_main) {
+        main_body(it, std::integral_constant<int, 0>{});
+        ++it;
+    }
+    // ---- columns past the image: only the right view is still working (no global loads) ----
+    for (; it < n_iter; ++it) {
+        unsigned* dst = reinterpret_cast<unsigned*>(&ring[slot * LD + sub * DPL]);
+#pragma unroll
+        for (int i = 0; i < DPL; i += 2) dst[i >> 1] = 0xFFFFFFFFu;
+        right_view(xa + it * COLS + px);
+        next_slot();
+    }
+}
+
+// ============================================================================================
+// right-view winner-take-all  (ref :374-443 with inverse == 1): cost of right pixel x at disparity d is
+// S[y][x+d][d], 65535 where x+d is off the image (ref :397-408).
+//
+// One lane = one right-view pixel; a workgroup handles WTA_T consecutive pixels of a row and walks the
+// disparity range in chunks of WTA_DC, staging the S columns x0+dmin+dc .. +T+DC-1 through LDS so the
+// diagonal gather reads conflict-free LDS (row stride 33 dwords) instead of strided HBM.  LDS reads are
+// issued 8 at a time so their latency overlaps the compare chain.
+// ============================================================================================
+
+#define WTA_T 256
+#define WTA_DC 64
+#define WTA_LD (WTA_DC + 2)       // u16 row stride (33 dwords: odd, conflict-free lane stride)
+
+__global__ __launch_bounds__(WTA_T) void sgm_wta_right_k(const uint16_t* __restrict__ S, float* __restrict__ disp_r, int W,
+                                                         int H, int D, int Dp, int dmin, int check_unique,
+                                                         float one_minus_ratio, int row0)
+{
+    __shared__ unsigned short tr[(WTA_T + WTA_DC) * WTA_LD];
+    const int row = row0 + blockIdx.y;
+    const int x0 = blockIdx.x * WTA_T;
+    const int i = threadIdx.x;
+    const int x = x0 + i;
+    const size_t frame_px = (size_t)blockIdx.z * W * H;                // batch: z = frame
+    const uint16_t* Srow = S + (frame_px + (size_t)row * W) * Dp;
+    disp_r += frame_px;
+
+    WtaState sr;
+    sr.m1 = sr.m2 = 0xFFFFu; sr.d1 = -1; sr.c1 = sr.c2 = 0xFFFFu; sr.pv = 0xFFFFu; sr.want_next = false;
+
+    for (int dc = 0; dc < D; dc += WTA_DC) {
+        __syncthreads();                                  // previous chunk fully consumed
+        // columns x0+dmin+dc .. +T+DC-2, disparities dc..dc+DC-1 in 16-byte pieces; off-image columns and
+        // disparities >= D read 65535 (ref :407; feeding 65535 never changes the state of a valid result)
+        for (int t = i; t < (WTA_T + WTA_DC) * (WTA_DC / 8); t += WTA_T) {
+            const int px = t / (WTA_DC / 8), piece = t % (WTA_DC / 8);
+            const int xx = x0 + dmin + dc + px;
+            const int d0 = dc + piece * 8;
+            uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            if (xx < W && d0 < Dp) {
+                v = *reinterpret_cast<const uint4*>(Srow + (size_t)xx * Dp + d0);
+                if (d0 + 8 > D) {                         // partially / fully padded piece
+                    unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        if (d0 + k >= D) w[k >> 1] |= (k & 1) ? 0xFFFF0000u : 0x0000FFFFu;
+                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            }
+            unsigned* dst = reinterpret_cast<unsigned*>(&tr[px * WTA_LD + piece * 8]);
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+        __syncthreads();
+        for (int e0 = 0; e0 < WTA_DC; e0 += 8) {
+            unsigned v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = tr[(i + e0 + k) * WTA_LD + e0 + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) wta_feed(sr, v[k], dc + e0 + k);
+        }
+    }
+    if (x < W) disp_r[(size_t)row * W + x] = wta_finish(sr, D, dmin, check_unique, one_minus_ratio);
+}
+
+// ============================================================================================
+// left-right consistency  (ref :445-470)
+// ============================================================================================
+
+__global__ __launch_bounds__(256) void sgm_lrcheck_k(float* __restrict__ dl, const float* __restrict__ dr, int W, int H,
+                                                     float thres, int row0)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = row0 + blockIdx.y;
+    if (x >= W) return;
+    const float inf = __builtin_inff();
+    dl += (size_t)blockIdx.z * W * H;                                   // batch: z = frame
+    dr += (size_t)blockIdx.z * W * H;
+    const size_t idx = (size_t)y * W + x;
+    const float d = dl[idx];
+    if (d == inf) return;
+    const int xr = (int)((double)((float)x - d) + 0.5);          // ref :454: float subtract, double add, truncate (Q12)
+    if (xr >= 0 && xr < W) {
+        const float r = dr[(size_t)y * W + xr];
+        if (r == inf) return;                                    // left kept
+        if (fabs((double)(d - r)) > (double)thres) dl[idx] = inf;
+    } else {
+        dl[idx] = inf;
+    }
+}
+
+template <int DPL, int THREADS>
+static void launch_sum_wta_lr(dim3 grid, hipStream_t st, const void* planes, size_t plane_bytes, int ndirs, const void* extras,
+                              const void* row_extras, const void* row_extra_count, int row_cap, int accumulate, int store_S,
+                              int do_right, void* S, void* disp_l, void* disp_r, const sgmd_geom* g, int check_unique,
+                              float one_minus_ratio, int seg_len)
+{
+#define SUMLR_CALL(SLOW)                                                                                              \
+    hipLaunchKernelGGL((sgm_sum_wta_lr_k<DPL, SLOW, THREADS>), grid, dim3(THREADS), 0, st, (const uint8_t*)planes, plane_bytes, ndirs, \
+                       (const uint8_t*)extras, (const sgmd_row_extra*)row_extras, (const int*)row_extra_count, row_cap,  \
+                       accumulate, store_S, do_right, (uint16_t*)S, (float*)disp_l, (float*)disp_r, g->W, g->H, g->D,    \
+                       g->dmin, check_unique, one_minus_ratio, g->row_begin, seg_len)
+    if (accumulate || store_S) SUMLR_CALL(true);
+    else SUMLR_CALL(false);
+#undef SUMLR_CALL
+}
+
+template <int DPL>
+static void launch_sum_wta(dim3 grid, hipStream_t st, const void* planes, size_t plane_bytes, int ndirs, const void* extras,
+                           const void* row_extras, const void* row_extra_count, int row_cap, int accumulate, void* S,
+                           void* disp_l, const sgmd_geom* g, int check_unique, float one_minus_ratio)
+{
+    hipLaunchKernelGGL((sgm_sum_wta_k<DPL>), grid, dim3(256), 0, st, (const uint8_t*)planes, plane_bytes, ndirs,
+                       (const uint8_t*)extras, (const sgmd_row_extra*)row_extras, (const int*)row_extra_count, row_cap,
+                       accumulate, (uint16_t*)S, (float*)disp_l, g->W, g->H, g->D, g->Dp, g->dmin, check_unique,
+                       one_minus_ratio, g->row_begin);
+}
+
+
+extern "C" {
+
+int sgmd_sum_wta(int ord, void* stream, const sgmd_geom* g, int ndirs, const void* planes, size_t plane_bytes,
+                 const void* extras, const void* row_extras, const void* row_extra_count, int row_cap, int accumulate,
+                 void* S, int check_unique, float one_minus_ratio, void* disp_l)
+{
+    HIP_TRY(hipSetDevice(ord));
+    const dim3 grid((g->W + 15) / 16, g->row_end - g->row_begin, g->B);
+    hipStream_t st = (hipStream_t)stream;
+#define SUM_ARGS grid, st, planes, plane_bytes, ndirs, extras, row_extras, row_extra_count, row_cap, accumulate, S, disp_l, g, check_unique, one_minus_ratio
+    switch (g->Dp / 16) {                                // 16 lanes per pixel here, whatever the aggregation used
+    case 2:  launch_sum_wta<2>(SUM_ARGS); break;
+    case 4:  launch_sum_wta<4>(SUM_ARGS); break;
+    case 8:  launch_sum_wta<8>(SUM_ARGS); break;
+    case 12: launch_sum_wta<12>(SUM_ARGS); break;
+    case 16: launch_sum_wta<16>(SUM_ARGS); break;
+    case 32: launch_sum_wta<32>(SUM_ARGS); break;
+    default:
+        fprintf(stderr, "sgm_mi355x: unsupported Dp %d\n", g->Dp);
+        return -1;
+    }
+#undef SUM_ARGS
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sgmd_sum_wta_lr_supported(const sgmd_geom* g, int row_cap)
+{
+    return (g->Dp == 32 || g->Dp == 64 || g->Dp == 128 || g->Dp == 192 || g->Dp == 256) && row_cap <= SUMLR_MAX_EXTRA;
+}
+
+int sgmd_sum_wta_lr(int ord, void* stream, const sgmd_geom* g, int ndirs, const void* planes, size_t plane_bytes,
+                    const void* extras, const void* row_extras, const void* row_extra_count, int row_cap, int accumulate,
+                    int store_S, int do_right, void* S, int check_unique, float one_minus_ratio, void* disp_l, void* disp_r)
+{
+    HIP_TRY(hipSetDevice(ord));
+    // segments per row: enough workgroups for ~4 per CU when a launch has few rows (one frame), but never segments
+    // shorter than 2 Dp columns (each re-sums dmin + D - 1 columns of its right neighbour), and one segment whenever S
+    // is read or written (the overlap would be accumulated twice)
+    const int rows = (g->row_end - g->row_begin) * g->B;
+    int segs = 1;
+    if (!accumulate && !store_S) {
+        const char* e = getenv("SGM_SUM_SEGMENTS");
+        segs = (e && *e) ? atoi(e) : (1024 + rows - 1) / rows;
+        if (segs > 4) segs = 4;
+        while (segs > 1 && g->W / segs < 2 * g->Dp) --segs;
+        if (segs < 1) segs = 1;
+    }
+    const int seg_len = (((g->W + segs - 1) / segs) + 15) / 16 * 16;
+    const dim3 grid(g->row_end - g->row_begin, g->B, (g->W + seg_len - 1) / seg_len);
+    hipStream_t st = (hipStream_t)stream;
+#define SUMLR_ARGS grid, st, planes, plane_bytes, ndirs, extras, row_extras, row_extra_count, row_cap, accumulate, store_S, do_right, S, disp_l, disp_r, g, check_unique, one_minus_ratio, seg_len
+    switch (g->Dp / 16) {
+    case 2: launch_sum_wta_lr<2, 256>(SUMLR_ARGS); break;
+    case 4: launch_sum_wta_lr<4, 256>(SUMLR_ARGS); break;
+    case 8: launch_sum_wta_lr<8, 256>(SUMLR_ARGS); break;   // (512 threads = 32 columns per iteration measured the same)
+    // larger ranges: the ring takes most of the CU's 160 KB of LDS, one workgroup per CU
+    case 12: launch_sum_wta_lr<12, 512>(SUMLR_ARGS); break;  // Dp 192: ring 256 x 194 u16 =  97 KB, 8 waves
+    case 16: launch_sum_wta_lr<16, 256>(SUMLR_ARGS); break;  // Dp 256: ring 288 x 258 u16 = 145 KB, 4 waves
+    default:
+        fprintf(stderr, "sgm_mi355x: fused sum/WTA needs Dp <= 256 (got %d)\n", g->Dp);
+        return -1;
+    }
+#undef SUMLR_ARGS
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sgmd_wta_right(int ord, void* stream, const sgmd_geom* g, const void* S, int check_unique, float one_minus_ratio,
+                   void* disp_r)
+{
+    HIP_TRY(hipSetDevice(ord));
+    dim3 grid((g->W + WTA_T - 1) / WTA_T, g->row_end - g->row_begin, g->B);
+    hipLaunchKernelGGL(sgm_wta_right_k, grid, dim3(WTA_T), 0, (hipStream_t)stream, (const uint16_t*)S, (float*)disp_r,
+                       g->W, g->H, g->D, g->Dp, g->dmin, check_unique, one_minus_ratio, g->row_begin);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sgmd_lrcheck(int ord, void* stream, const sgmd_geom* g, void* disp_l, const void* disp_r, float thres)
+{
+    HIP_TRY(hipSetDevice(ord));
+    dim3 grid((g->W + 255) / 256, g->row_end - g->row_begin, g->B);
+    hipLaunchKernelGGL(sgm_lrcheck_k, grid, dim3(256), 0, (hipStream_t)stream, (float*)disp_l, (const float*)disp_r,
+                       g->W, g->H, thres, g->row_begin);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"
