@@ -14,6 +14,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The reference-vs-oracle tests need oracle/_ref (the reference compiled from its own sources, git-ignored).
+    # Where the reference is mounted and the libraries are missing, build them now (3 gcc runs, a few seconds);
+    # on the GPU box there is no reference and those tests skip.
+    ref_src = os.path.join(os.environ.get("SGM_REFERENCE_DIR", "/root/reference"), "SemiGlobalMatching")
+    if os.path.isdir(ref_src) and not os.path.isdir(os.path.join(ROOT, "oracle", "_ref")):
+        import subprocess
+        subprocess.call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "ref"], stdout=subprocess.DEVNULL)
 
 
 @pytest.fixture(scope="session")
