@@ -17,6 +17,14 @@ def pytest_configure(config):
     # The reference-vs-oracle tests need oracle/_ref (the reference compiled from its own sources, git-ignored).
     # Where the reference is mounted and the libraries are missing, build them now (3 gcc runs, a few seconds);
     # on the GPU box there is no reference and those tests skip.
+    import shutil
+    lib = os.path.join(ROOT, "soc_project_stereo_matching_amd", "libsgm_mi355x.so")
+    if not os.path.exists(lib) and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        # a fresh checkout: the library is git-ignored; cross-compile it (no GPU needed, ~40 s) so that the C-ABI
+        # tests have something to load.  The product itself never builds or falls back at run time.
+        import subprocess
+        subprocess.call(["make", "-s", "-j4", "-C", os.path.join(ROOT, "soc_project_stereo_matching_amd", "csrc")],
+                        stdout=subprocess.DEVNULL)
     ref_src = os.path.join(os.environ.get("SGM_REFERENCE_DIR", "/root/reference"), "SemiGlobalMatching")
     if os.path.isdir(ref_src) and not os.path.isdir(os.path.join(ROOT, "oracle", "_ref")):
         import subprocess
