@@ -176,7 +176,7 @@ def match_tiled(engine: TileEngine, rank: int, world: int, left, right, height: 
 
     mine = engine.finish()
     if world == 1:
-        full = mine
+        full = mine.clone()                                      # not a view of the engine's own buffer
     else:
         for l in links:
             l.drain()
@@ -214,5 +214,5 @@ def match_tiled_in_process(engines, left, right):
             if not last:
                 buf = engines[k].new_boundary()
                 engines[k].export_boundary(forward, buf)
-    full = torch.cat([e.finish() for e in engines], dim=0) if n > 1 else engines[0].finish()
+    full = torch.cat([e.finish() for e in engines], dim=0) if n > 1 else engines[0].finish().clone()
     return engines[0].post(full.contiguous())
