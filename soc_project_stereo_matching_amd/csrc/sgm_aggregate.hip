@@ -25,7 +25,6 @@ struct AggArgs {
     int W, H, D, Dp;
     int row_begin, row_end;     // rows of the frame this launch covers (a row tile of a multi-GPU run; [0,H) normally)
     int run_anom;               // 1: also run the four anomalous diagonal lines (whole frame)
-    int probe_no_store;         // PERF PROBE ONLY (SGM_PROBE_NO_PLANE_STORES): skip the plane stores
     int B;                      // frames per launch; frame f uses img/census + f*W*H, planes + f*8*plane_bytes, extras + f*4*H*Dp
     int p1;
     int ndirs;
@@ -171,7 +170,7 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
     const int sub = lane & (LPP - 1);
     const bool first_lane = (sub == 0), last_lane = (sub == LPP - 1);
     int line = grp * LPW + lane / LPP;
-    bool store_ok = line < nlines && !a.probe_no_store;
+    bool store_ok = line < nlines;
     if (!store_ok) line = nlines - 1;                                      // keep the wave convergent; stores are masked
     if (KIND == AGG_D && line == a.anom_line[dir]) {                       // handled by agg_anomalous()
         store_ok = false;
@@ -523,7 +522,6 @@ int sgmd_aggregate(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* 
     a.extras = (uint8_t*)extras;
     a.W = g->W; a.H = g->H; a.D = g->D; a.Dp = g->Dp;
     a.B = g->B;
-    { const char* e = getenv("SGM_PROBE_NO_PLANE_STORES"); a.probe_no_store = (e && atoi(e)) ? 1 : 0; }
     a.row_begin = g->row_begin; a.row_end = g->row_end;
     a.run_anom = (paths->ndirs > 4 && paths->run_anom) ? 1 : 0;
     a.p1 = paths->p1;
