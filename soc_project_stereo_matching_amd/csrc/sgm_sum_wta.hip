@@ -165,7 +165,14 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
     const int x_last = do_right ? xb - 1 + dmin + D - 1 : xb - 1;       // last column any pixel of the segment needs
     const int n_main = (min(x_last + 1, W) - xa + COLS - 1) / COLS;
     const int n_iter = (x_last - xa) / COLS + 1;
-    const unsigned upper_mask = (ndirs > 4) ? 0xFFu : 0u;               // planes 4..7 count only with eight paths
+    // planes 4..7 count only with eight paths (with four they re-read planes 0..3, see sumlr_prefetch): byte-extraction
+    // mask / selector that give zeros then
+    const unsigned upper_lo = (ndirs > 4) ? 0x00FF00FFu : 0u;
+    const unsigned upper_sel = (ndirs > 4) ? 0x0c030c01u : 0x0c0c0c0cu;
+    unsigned padpair[DPL / 2];                                          // 65535 in the halves of padding disparities
+#pragma unroll
+    for (int m = 0; m < DPL / 2; ++m)
+        padpair[m] = ((sub * DPL + 2 * m >= D) ? 0xFFFFu : 0u) | ((sub * DPL + 2 * m + 1 >= D) ? 0xFFFF0000u : 0u);
 
     auto cell_off = [&](int x) { return row_cells + (size_t)min(x, W - 1) * Dp + sub * DPL; };
     CellVec<DPL> pre[2][8];
@@ -232,37 +239,68 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
         const bool inside = x < W;
         const bool mine = x < xb;                                        // left-view output (and S) of this segment
         const size_t off = cell_off(x);
-        unsigned acc[DPL];
+        // S of this lane's DPL disparities as packed u16 pairs: aL[k] = (S(4k), S(4k+2)), aH[k] = (S(4k+1), S(4k+3)) --
+        // a plane dword gives both with one AND and one v_perm, and eight planes add up in 16-bit halves without
+        // carries (8 x 255 + a few anomalous visits < 2^16; the accumulating variant adds with v_pk_add_u16, where
+        // the reference's uint16 sums may wrap)
+        constexpr int NW = (DPL + 3) / 4;
+        constexpr int NPAIR = DPL / 2;
+        unsigned aL[NW], aH[NW];
 #pragma unroll
-        for (int i = 0; i < DPL; ++i) acc[i] = 0;
+        for (int k = 0; k < NW; ++k) aL[k] = aH[k] = 0;
+        auto add_packed = [&](unsigned& dst, unsigned v) {
+            if (SLOW) dst = as_u(as_p(dst) + as_p(v));                   // per-half wrap (Q14 sums are uint16)
+            else dst += v;
+        };
+        auto add_bytes = [&](int k, unsigned w, unsigned mask_lo, unsigned sel_hi) {
+            add_packed(aL[k], w & mask_lo);                              // bytes 0, 2
+            add_packed(aH[k], __builtin_amdgcn_perm(0u, w, sel_hi));     // bytes 1, 3
+        };
         if (SLOW) {
             if (accumulate) {                                            // Q14: S was not reset since the last frame
+                const unsigned* sp = reinterpret_cast<const unsigned*>(S + off);
+                if constexpr (DPL == 2) {
+                    const unsigned v = sp[0];
+                    aL[0] = v & 0xFFFFu; aH[0] = v >> 16;
+                } else {
 #pragma unroll
-                for (int i = 0; i < DPL; ++i) acc[i] = S[off + i];
+                    for (int k = 0; k < NW; ++k) {
+                        const unsigned e = sp[2 * k], o = sp[2 * k + 1]; // (S(4k), S(4k+1)), (S(4k+2), S(4k+3))
+                        aL[k] = __builtin_amdgcn_perm(o, e, 0x05040100u);
+                        aH[k] = __builtin_amdgcn_perm(o, e, 0x07060302u);
+                    }
+                }
             }
         }
 #pragma unroll
         for (int d = 0; d < 8; ++d) {
-            const unsigned m = (d < 4) ? 0xFFu : upper_mask;
+            const unsigned mask_lo = (d < 4) ? 0x00FF00FFu : upper_lo;
+            const unsigned sel_hi = (d < 4) ? 0x0c030c01u : upper_sel;
 #pragma unroll
-            for (int i = 0; i < DPL; ++i) acc[i] += (pre[STAGE][d].w[i >> 2] >> (8 * (i & 3))) & m;
+            for (int k = 0; k < NW; ++k) add_bytes(k, pre[STAGE][d].w[k], mask_lo, sel_hi);
         }
         sumlr_prefetch<DPL, STAGE>(pre, planes, plane_bytes, ndirs, cell_off(x + 2 * COLS));     // columns of iteration it + 2
         for (int j = 0; j < n_extra; ++j) {
             if (ex_col[j] == x) {                                        // second visit of an anomalous line (LDS)
+                if constexpr (DPL == 2) {
+                    const unsigned w = (ex_val[j * (Dp / 4) + (sub >> 1)] >> (16 * (sub & 1))) & 0xFFFFu;
+                    add_bytes(0, w, 0x00FF00FFu, 0x0c030c01u);
+                } else {
 #pragma unroll
-                for (int i = 0; i < DPL; ++i) {
-                    const int b = sub * DPL + i;
-                    acc[i] += (ex_val[j * (Dp / 4) + (b >> 2)] >> (8 * (b & 3))) & 0xFF;
+                    for (int k = 0; k < NW; ++k) add_bytes(k, ex_val[j * (Dp / 4) + sub * (DPL / 4) + k], 0x00FF00FFu, 0x0c030c01u);
                 }
             }
         }
+        // back to disparity order: pr[m] = (S(2m), S(2m+1))
+        unsigned pr[NPAIR];
+#pragma unroll
+        for (int m = 0; m < NPAIR; ++m)
+            pr[m] = __builtin_amdgcn_perm(aH[m >> 1], aL[m >> 1], (m & 1) ? 0x07060302u : 0x05040100u);
         if (SLOW) {
             if (store_S && mine) {
-                unsigned short* dst = S + off;
+                unsigned* dst = reinterpret_cast<unsigned*>(S + off);
 #pragma unroll
-                for (int i = 0; i < DPL; i += 2)
-                    *reinterpret_cast<unsigned*>(dst + i) = (acc[i] & 0xFFFFu) | (acc[i + 1] << 16);
+                for (int m = 0; m < NPAIR; ++m) dst[m] = pr[m];
             }
         }
         // ---- this column's S vector into the ring (65535 outside the image / the disparity range) ----
@@ -271,21 +309,21 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
         {
             unsigned* dst = reinterpret_cast<unsigned*>(&ring[slot * LD + sub * DPL]);
 #pragma unroll
-            for (int i = 0; i < DPL; i += 2) {
-                const int idx = sub * DPL + i;
-                const unsigned lo = (inside && idx < D) ? (acc[i] & 0xFFFFu) : 0xFFFFu;
-                const unsigned hi = (inside && idx + 1 < D) ? (acc[i + 1] & 0xFFFFu) : 0xFFFFu;
-                dst[i >> 1] = lo | (hi << 16);
+            for (int m = 0; m < NPAIR; ++m) {
+                pr[m] = inside ? (pr[m] | padpair[m]) : 0xFFFFFFFFu;
+                dst[m] = pr[m];
             }
         }
-        // ---- left-view WTA over the 16 lanes of the pixel (as in sgm_sum_wta_k) ----
+        // ---- left-view WTA over the 16 lanes of the pixel (as in sgm_sum_wta_k); padding disparities carry 65535,
+        //      so their keys lose against every real one ----
         unsigned key[DPL];
         unsigned kmin = 0xFFFFFFFFu;
 #pragma unroll
-        for (int i = 0; i < DPL; ++i) {
-            const int idx = sub * DPL + i;
-            key[i] = (idx < D) ? (((acc[i] & 0xFFFFu) << 16) | (unsigned)idx) : 0xFFFFFFFFu;
-            kmin = min(kmin, key[i]);
+        for (int m = 0; m < NPAIR; ++m) {
+            const unsigned idx = (unsigned)(sub * DPL + 2 * m);
+            key[2 * m] = (pr[m] << 16) | idx;
+            key[2 * m + 1] = (pr[m] & 0xFFFF0000u) | (idx + 1);
+            kmin = min(kmin, min(key[2 * m], key[2 * m + 1]));
         }
         const unsigned kbest = row_allmin<16>(kmin);
         const unsigned nbest = ~kbest;                                   // runner-up as in right_view()
@@ -300,7 +338,7 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
             WtaState st;
             st.m1 = kbest >> 16;
             st.m2 = ksecond >> 16;
-            st.d1 = (kbest == 0xFFFFFFFFu) ? -1 : dbest;
+            st.d1 = dbest;
             st.c1 = ring[slot * LD + km];                                // S[best-1], S[best+1] (unused when best is at an end)
             st.c2 = ring[slot * LD + kp];
             st.pv = 0; st.want_next = false;
