@@ -181,11 +181,16 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
 
     int slot = px;                                                       // ring slot of this thread's column: x mod R
 
-    // right-view WTA of the pixel whose last column (disparity D-1) is column x, after the ring holds column x
-    auto right_view = [&](int x) {
-        __syncthreads();                                                 // the new columns are in the ring
+    // Both views end in ONE wta_finish per iteration (uniqueness test, float divide of the sub-pixel term: ~35
+    // instructions a wave pays in full even for a single active lane): lane 0 of a pixel finishes the left view,
+    // lane 1 the right view.  kl/ks = best and runner-up key of the left view of column x (ignored unless `left`).
+    auto finish_views = [&](int x, bool left, unsigned kl, unsigned ks) {
+        unsigned kbest_r = 0, ksecond_r = 0;
+        int base = 0;
         const int xr = x - dmin - (D - 1);
-        int base = slot + R - (D - 1);                                   // ring slot of column xr + dmin = x - (D-1)
+        if (do_right) {
+        __syncthreads();                                                 // the new columns are in the ring
+        base = slot + R - (D - 1);                                       // ring slot of column xr + dmin = x - (D-1)
         if (base >= R) base -= R;
         unsigned key[DPL], val[DPL];
         unsigned kmin = 0xFFFFFFFFu;
@@ -209,23 +214,30 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
         unsigned k2 = 0xFFFFFFFFu;
 #pragma unroll
         for (int i = 0; i < DPL; ++i) k2 = min(k2, key[i] + nbest);
-        const unsigned ksecond = row_allmin<16>(k2) + kbest + 1;
-        const int dbest = (int)(kbest & 0xFFFFu);
-        if (xr >= xa && xr < xb && sub == 0) {
-            // S[best-1], S[best+1] straight from the ring (a best at either end of the range is invalid anyway,
-            // ref :428: clamp the index, the value is not used)
+        kbest_r = kbest;
+        ksecond_r = row_allmin<16>(k2) + kbest + 1;
+        }
+        const bool is_r = (sub == 1);
+        const bool active = is_r ? (do_right && xr >= xa && xr < xb) : (sub == 0 && left);
+        if (active) {
+            const unsigned kb = is_r ? kbest_r : kl, k2nd = is_r ? ksecond_r : ks;
+            const int dbest = (int)(kb & 0xFFFFu);
+            // S[best-1], S[best+1] straight from the ring: the column's own slot for the left view, the diagonal for
+            // the right one (a best at either end of the range is invalid anyway, ref :428: clamp, value unused)
             const int km = max(dbest - 1, 0), kp = min(dbest + 1, Dp - 1);
             int sm = base + km, sp = base + kp;
             if (sm >= R) sm -= R;
             if (sp >= R) sp -= R;
+            if (!is_r) sm = sp = slot;
             WtaState st;
-            st.m1 = kbest >> 16;
-            st.m2 = ksecond >> 16;
-            st.d1 = ((kbest >> 16) == 0xFFFFu) ? -1 : dbest;             // nothing beat 65535 (ref :381, strict '>')
+            st.m1 = kb >> 16;
+            st.m2 = k2nd >> 16;
+            st.d1 = (is_r && (kb >> 16) == 0xFFFFu) ? -1 : dbest;        // right view: nothing beat 65535 (ref :381, strict '>')
             st.c1 = ring[sm * LD + km];
             st.c2 = ring[sp * LD + kp];
             st.pv = 0; st.want_next = false;
-            disp_r[(size_t)row * W + xr] = wta_finish(st, D, dmin, check_unique, one_minus_ratio);
+            float* const out = is_r ? disp_r + xr : disp_l + x;
+            out[(size_t)row * W] = wta_finish(st, D, dmin, check_unique, one_minus_ratio);
         }
     };
     auto next_slot = [&]() {
@@ -331,20 +343,8 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
 #pragma unroll
         for (int i = 0; i < DPL; ++i) k2 = min(k2, key[i] + nbest);
         const unsigned ksecond = row_allmin<16>(k2) + kbest + 1;
-        const int dbest = (int)(kbest & 0xFFFFu);
         asm volatile("" ::: "memory");                                   // the wave's ring writes above stay above
-        if (mine && sub == 0) {
-            const int km = max(dbest - 1, 0), kp = min(dbest + 1, Dp - 1);
-            WtaState st;
-            st.m1 = kbest >> 16;
-            st.m2 = ksecond >> 16;
-            st.d1 = dbest;
-            st.c1 = ring[slot * LD + km];                                // S[best-1], S[best+1] (unused when best is at an end)
-            st.c2 = ring[slot * LD + kp];
-            st.pv = 0; st.want_next = false;
-            disp_l[(size_t)row * W + x] = wta_finish(st, D, dmin, check_unique, one_minus_ratio);
-        }
-        if (do_right) right_view(x);
+        finish_views(x, mine, kbest, ksecond);
         next_slot();
     };
 
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
         unsigned* dst = reinterpret_cast<unsigned*>(&ring[slot * LD + sub * DPL]);
 #pragma unroll
         for (int i = 0; i < DPL; i += 2) dst[i >> 1] = 0xFFFFFFFFu;
-        right_view(xa + it * COLS + px);
+        finish_views(xa + it * COLS + px, false, 0u, 0u);
         next_slot();
     }
 }
