@@ -224,6 +224,9 @@ def main():
                     per_frame = json.load(f).get(args.workload, {}).get("sgm_aggregate_k")
                 if per_frame:
                     roofline["traffic"] = int(per_frame) * B
+                    # the same launch priced with the bytes it really moves (what an HBM-bound kernel would be judged by)
+                    roofline["traffic_GBps"] = round(roofline["traffic"] / (agg_ms * 1e-3) / 1e9, 1)
+                    roofline["traffic_frac"] = round(roofline["traffic_GBps"] / HBM_PEAK_GBS, 4)
         # the other heavy kernel: cost sum + both WTAs, a pure HBM stream of the 8 planes (measured bytes, PMC)
         sum_roofline = None
         sum_ms = stage_ms.get("sum")
