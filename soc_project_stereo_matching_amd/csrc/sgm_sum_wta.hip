@@ -103,9 +103,9 @@ __global__ __launch_bounds__(256) void sgm_sum_wta_k(const uint8_t* __restrict__
 // ============================================================================================
 template <int DPL, int STAGE>
 static __device__ __forceinline__ void sumlr_prefetch(CellVec<DPL> (&pre)[2][8], const uint8_t* planes, size_t plane_bytes,
-                                                      int ndirs, size_t off)
+                                                      int ndirs, unsigned off)
 {
-    // always 8 unconditional loads (see SLOW below): with four paths the upper four re-read planes 0..3 and are
+    // always 8 unconditional loads (uniform plane base + 32-bit lane offset: no 64-bit address arithmetic per load) (see SLOW below): with four paths the upper four re-read planes 0..3 and are
     // masked out when they are added
 #pragma unroll
     for (int d = 0; d < 8; ++d)
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
     S += (size_t)blockIdx.y * W * H * Dp;
     disp_l += (size_t)blockIdx.y * W * H;
     disp_r += (size_t)blockIdx.y * W * H;
-    const size_t row_cells = (size_t)row * W * Dp;
+    const unsigned row_cells = (unsigned)row * (unsigned)W * Dp;      // 32-bit cell offsets: the host guarantees W*H*Dp < 2^32
     const int n_extra = (ndirs > 4) ? min(row_extra_count[row], SUMLR_MAX_EXTRA) : 0;    // host: row_cap <= SUMLR_MAX_EXTRA
     for (int t = threadIdx.x; t < n_extra * (Dp / 4); t += THREADS) {
         const int j = t / (Dp / 4), w = t % (Dp / 4);
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
     for (int m = 0; m < DPL / 2; ++m)
         padpair[m] = ((sub * DPL + 2 * m >= D) ? 0xFFFFu : 0u) | ((sub * DPL + 2 * m + 1 >= D) ? 0xFFFF0000u : 0u);
 
-    auto cell_off = [&](int x) { return row_cells + (size_t)min(x, W - 1) * Dp + sub * DPL; };
+    auto cell_off = [&](int x) { return row_cells + (unsigned)min(x, W - 1) * Dp + (unsigned)(sub * DPL); };
     CellVec<DPL> pre[2][8];
     sumlr_prefetch<DPL, 0>(pre, planes, plane_bytes, ndirs, cell_off(xa + px));
     sumlr_prefetch<DPL, 1>(pre, planes, plane_bytes, ndirs, cell_off(xa + COLS + px));
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
         const int x = xa + it * COLS + px;
         const bool inside = x < W;
         const bool mine = x < xb;                                        // left-view output (and S) of this segment
-        const size_t off = cell_off(x);
+        const unsigned off = cell_off(x);
         // S of this lane's DPL disparities as packed u16 pairs: aL[k] = (S(4k), S(4k+2)), aH[k] = (S(4k+1), S(4k+3)) --
         // a plane dword gives both with one AND and one v_perm, and eight planes add up in 16-bit halves without
         // carries (8 x 255 + a few anomalous visits < 2^16; the accumulating variant adds with v_pk_add_u16, where
