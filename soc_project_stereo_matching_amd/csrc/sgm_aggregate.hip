@@ -1,508 +1,7 @@
-#include "sgm_common.hpp"
+#include "sgm_aggregate_impl.hpp"
 
-// ============================================================================================
-// path aggregation  (ref :198-372)
-//
-// One wave = 4 path lines (one per 16-lane DPP row); lane `sub` of a row owns DPL consecutive
-// disparities, kept as DPL/2 packed u16 pairs.  Per step and line:
-//   L(d) = u8( C(d) + min( Lp(d), Lp(d-1)+P1, Lp(d+1)+P1, minPrev + pen ) - minPrev )
-// with Lp(-1) = Lp(D) = 255 (ref :260-263), all sums truncated to u16 as in the C (ref :332-335)
-// and the result truncated to u8 (ref :343, Q7).  d+-1 neighbours of the lane-edge elements come
-// from DPP row shifts; min over d is an in-lane tree plus a 4-step DPP all-reduce.  All
-// directions run in one launch; every line walks the image with the reference's own pointer
-// state machine (ref :281-323, 359-367), so wrap-around diagonals (Q5) need no special casing.
-// ============================================================================================
-
-struct AggArgs {
-    const uint8_t* img;
-    const uint32_t* census_l;
-    const uint32_t* census_r;   // the allocation has >= dmin + Dp dwords of slack in front (reads left of column 0)
-    int dmin;
-    const uint16_t* lut;        // (uint16) max(P1, P2 / (|dg| + 1)), 256 entries (ref :335)
-    uint8_t* planes;
-    size_t plane_bytes;
-    uint8_t* extras;
-    int W, H, D, Dp;
-    int row_begin, row_end;     // rows of the frame this launch covers (a row tile of a multi-GPU run; [0,H) normally)
-    int run_anom;               // 1: also run the four anomalous diagonal lines (whole frame)
-    int B;                      // frames per launch; frame f uses img/census + f*W*H, planes + f*8*plane_bytes, extras + f*4*H*Dp
-    int p1;
-    int ndirs;
-    int dx[8], dy[8];
-    int anom_line[8];
-    int block_begin[9];
-    int ghost_zero;
-};
-
-// per-frame base pointers of a batched launch (kept apart from the kernel-argument struct so that struct
-// stays in the scalar kernarg segment)
-struct AggFrame {
-    const uint8_t* img;
-    const uint32_t* census_l;
-    const uint32_t* census_r;
-    uint8_t* planes;
-    uint8_t* extras;
-};
-
-// The matching cost is recomputed here from the two census images instead of being read from a
-// materialised cost volume: C(p,d) = popcount(cl[y][x] ^ cr[y][x-d]), 127 where x-d is left of the image
-// (ref :161-196).  The census images (2 x 1.9 MB at KITTI) stay in L2, so the 8 directions no longer
-// stream the 60 MB volume from HBM eight times.
-//
-// CensusVec holds, for the DPL disparities of a lane, the census-right words in ASCENDING ADDRESS order:
-// r[j] = cr[y][x - dmin - lane_off - (DPL-1) + j], i.e. r[DPL-1-i] belongs to the lane's i-th disparity.
-template <int DPL> struct CensusVec { unsigned r[DPL]; };
-
-template <int DPL>
-static __device__ __forceinline__ void load_census(const uint32_t* p, CensusVec<DPL>& v)
-{
-    if constexpr (DPL == 2) {
-        struct __attribute__((packed, aligned(4))) u2 { unsigned a, b; };
-        const u2 t = *reinterpret_cast<const u2*>(p);
-        v.r[0] = t.a; v.r[1] = t.b;
-    } else {
-        struct __attribute__((packed, aligned(4))) u4 { unsigned a, b, c, d; };
-#pragma unroll
-        for (int q = 0; q < DPL / 4; ++q) {
-            const u4 t = *reinterpret_cast<const u4*>(p + 4 * q);
-            v.r[4 * q] = t.a; v.r[4 * q + 1] = t.b; v.r[4 * q + 2] = t.c; v.r[4 * q + 3] = t.d;
-        }
-    }
-}
-
-// packed u16 cost pairs of a lane.  `lim` = x - dmin - lane_off: disparity i of the lane is inside the
-// image iff i <= lim; `masked` (wave-uniform) says whether any lane of the wave needs the test at all.
-template <int DPL>
-static __device__ __forceinline__ void census_costs(unsigned cl, const CensusVec<DPL>& cv, int lim, bool masked,
-                                                    us2 (&C)[DPL / 2])
-{
-#pragma unroll
-    for (int j = 0; j < DPL / 2; ++j) {
-        const unsigned hi = (unsigned)__popc(cl ^ cv.r[DPL - 2 - 2 * j]) << 16;
-        C[j] = as_p((unsigned)__popc(cl ^ cv.r[DPL - 1 - 2 * j]) + hi);
-    }
-    if (masked) {
-#pragma unroll
-        for (int j = 0; j < DPL / 2; ++j) {
-            const unsigned m = (2 * j > lim ? 0xFFFFu : 0u) | (2 * j + 1 > lim ? 0xFFFF0000u : 0u);
-            C[j] = as_p((as_u(C[j]) & ~m) | (0x007F007Fu & m));           // UINT8_MAX/2 (ref :170-171)
-        }
-    }
-}
-
-// One aggregation step for the 4 lines of a wave: returns the new packed L_r in Ln and the new
-// row minimum; Lp/min_prev are the previous pixel's (ref :329-353).
-template <int DPL, bool PAD, int LPP>
-static __device__ __forceinline__ unsigned agg_step(const us2 (&C)[DPL / 2], us2 (&Lp)[DPL / 2], unsigned min_prev,
-                                                    unsigned pen16, us2 p1v, const us2 (&padmask)[DPL / 2],
-                                                    bool first_lane, bool last_lane, CellVec<DPL>& packed_out)
-{
-    constexpr int NP = DPL / 2;
-    const unsigned l4u = (min_prev + pen16) & 0xFFFFu;                     // ref :335, truncated to u16
-    const us2 l4 = as_p(l4u | (l4u << 16));
-    const us2 mp = as_p(min_prev | (min_prev << 16));
-    // d-1 / d+1 neighbours across the lane boundary; 255 where there is none (ref :260-263)
-    unsigned from_left, from_right;
-    if (LPP >= 32) {                                    // a pixel spans several DPP rows: shift across the whole wave
-        from_left = dpp_mov<0x138 /* wave_shr:1 */>(0x00FF00FFu, as_u(Lp[NP - 1]));
-        from_right = dpp_mov<0x130 /* wave_shl:1 */>(0x00FF00FFu, as_u(Lp[0]));
-    } else {
-        from_left = dpp_mov<DPP_ROW_SHR1>(0x00FF00FFu, as_u(Lp[NP - 1]));
-        from_right = dpp_mov<DPP_ROW_SHL1>(0x00FF00FFu, as_u(Lp[0]));
-    }
-    if (LPP != 16) {                                    // pixel boundaries that are not DPP row boundaries: cut the shift there
-        from_left = first_lane ? 0x00FF00FFu : from_left;
-        from_right = last_lane ? 0x00FF00FFu : from_right;
-    }
-    us2 Ln[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        const unsigned below = (j == 0) ? from_left : as_u(Lp[j - 1]);
-        const unsigned above = (j == NP - 1) ? from_right : as_u(Lp[j + 1]);
-        const us2 dm1 = as_p(__builtin_amdgcn_alignbit(as_u(Lp[j]), below, 16));   // (Lp(d-1), Lp(d))   pairs
-        const us2 dp1 = as_p(__builtin_amdgcn_alignbit(above, as_u(Lp[j]), 16));   // (Lp(d+1), Lp(d+2))
-        us2 m = pk_min(dm1 + p1v, dp1 + p1v);           // l2, l3 (ref :333-334), each truncated to u16
-        m = pk_min(m, Lp[j]);                           // l1
-        m = pk_min(m, l4);
-        const us2 wide = (C[j] - mp) + m;               // mod 2^16 == the C's int arithmetic mod 2^16
-        unsigned r = as_u(wide) & 0x00FF00FFu;          // ref :343 uint8 truncation (Q7)
-        if (PAD) r |= as_u(padmask[j]);
-        Ln[j] = as_p(r);
-    }
-    us2 m = Ln[0];
-#pragma unroll
-    for (int j = 1; j < NP; ++j) m = pk_min(m, Ln[j]);
-#pragma unroll
-    for (int j = 0; j < NP; ++j) Lp[j] = Ln[j];
-    pack_cells<DPL>(Ln, packed_out);
-    return row_allmin<LPP>(min(as_u(m) & 0xFFFFu, as_u(m) >> 16));        // ref :347,353
-}
-
-enum { AGG_H = 0, AGG_V = 1, AGG_D = 2 };
-
-// Regular lines of one direction kind.  All addressing is 32-bit offsets from the volume bases
-// (the host guarantees W*H*Dp < 2^32); the walk is the reference's (ref :281-323, 359-367) with the
-// row test dropped (a regular line is never in the last row before its final step) and the two
-// edge tests turned into selects.
-template <int DPL, bool PAD, int LPP, int KIND>
-static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFrame& fr, const unsigned short* lut_s,
-                                                   int dir, int grp)
-{
-    constexpr int NP = DPL / 2;
-    constexpr int PF = (LPP >= 32) ? 4 : 2;                              // prefetch depth (steps): 2 keeps the 8-lines-per-wave kernel at 8 waves/SIMD; the latency-critical 32-lane lines look further ahead
-    const int lane = threadIdx.x;
-    const int dx = a.dx[dir], dy = a.dy[dir];
-    const int W = a.W, H = a.H, Dp = a.Dp;
-    const bool fwd = (dx == 1 && dy == 0) || (dx == 0 && dy == 1) || (dx == 1 && dy == 1) || (dx == -1 && dy == 1);  // ref :232
-    const int s = fwd ? 1 : -1;
-    // Row tile [row_begin, row_end): horizontal lines are the tile's rows; a vertical / diagonal line enters the
-    // tile with the path state of its previous pixel, read from the row just outside the tile in this direction's
-    // plane (written by the neighbouring GPU and copied in), or starts with L = C where the tile touches the frame
-    // edge the direction starts from.  [0,H) = the whole frame = the reference's walk.
-    const int rows = a.row_end - a.row_begin;
-    const int skip = (KIND == AGG_H) ? 0 : (fwd ? a.row_begin : H - a.row_end);    // rows between that edge and the tile
-    const bool import_state = skip > 0;
-    const int nlines = (KIND == AGG_H) ? rows : W;                         // ref :238
-    const int nsteps = (KIND == AGG_H) ? W - 1 : (import_state ? rows : rows - 1);   // ref :281
-    if (KIND == AGG_D && W < 2) return;                                    // the only line is the anomalous one
-
-    constexpr int LPW = 64 / LPP;                                          // path lines per wave
-    const int sub = lane & (LPP - 1);
-    const bool first_lane = (sub == 0), last_lane = (sub == LPP - 1);
-    int line = grp * LPW + lane / LPP;
-    bool store_ok = line < nlines;
-    if (!store_ok) line = nlines - 1;                                      // keep the wave convergent; stores are masked
-    if (KIND == AGG_D && line == a.anom_line[dir]) {                       // handled by agg_anomalous()
-        store_ok = false;
-        line = (line == 0) ? 1 : line - 1;
-    }
-    const unsigned lane_off = (unsigned)(sub * DPL);
-    uint8_t* const plane = fr.planes + (size_t)dir * a.plane_bytes;
-
-    us2 padmask[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        const unsigned lo = ((int)lane_off + 2 * j >= a.D) ? 0x00FFu : 0u;
-        const unsigned hi = ((int)lane_off + 2 * j + 1 >= a.D) ? 0x00FF0000u : 0u;
-        padmask[j] = as_p(lo | hi);
-    }
-
-    // fetch cursor: pixel index p (grey value, census), true column x and byte offset of this lane's cells
-    unsigned p, off;
-    int x;
-    unsigned rowpix = 0, rowoff = 0, pcol = 0, col = 0;                    // AGG_D only
-    int dstep_p = 0, dstep_off = 0;
-    if (KIND == AGG_H) {
-        x = fwd ? 0 : W - 1;
-        p = (unsigned)((a.row_begin + line) * W + x);
-        dstep_p = s; dstep_off = s * Dp;
-    } else if (KIND == AGG_V) {
-        x = line;
-        // first row of the tile in walking order, or (import) the row before it
-        const int r = fwd ? a.row_begin - (import_state ? 1 : 0) : a.row_end - 1 + (import_state ? 1 : 0);
-        p = (unsigned)(r * W + line);
-        dstep_p = s * W; dstep_off = s * W * Dp;
-    } else {
-        rowpix = (unsigned)(fwd ? 0 : (H - 1) * W);
-        rowoff = rowpix * (unsigned)Dp;
-        pcol = col = (unsigned)line;
-        x = line;
-        p = rowpix + pcol;
-        dstep_p = s * W; dstep_off = s * W * Dp;
-    }
-    off = p * (unsigned)Dp + lane_off;
-    const int col_step = (dx == dy) ? s : -s;                              // ref :360-367
-    // census-right words of this lane's disparities start (ascending addresses) at pixel p - back
-    const int back = a.dmin + (int)lane_off + DPL - 1;
-    const int lim_bias = a.dmin + (int)lane_off;                           // disparity i of the lane is in the image iff i <= x - lim_bias
-
-    auto advance = [&]() {
-        if (KIND == AGG_H) {
-            p += (unsigned)dstep_p;
-            off += (unsigned)dstep_off;
-            x += s;
-        } else if (KIND == AGG_V) {
-            p += (unsigned)dstep_p;
-            off += (unsigned)dstep_off;
-        } else {
-            const bool wr = (col == (unsigned)(W - 1));                    // ref :297 (tracker, not true column)
-            const bool wl = !wr && (col == 0);                             // ref :304
-            pcol = wr ? 0u : (wl ? (unsigned)(W - 1) : pcol + (unsigned)col_step);
-            col = ((wr ? 0u : (wl ? (unsigned)(W - 1) : col)) + (unsigned)col_step) & 0xFFFFu;
-            rowpix += (unsigned)dstep_p;
-            rowoff += (unsigned)dstep_off;
-            p = rowpix + pcol;
-            x = (int)pcol;
-            off = rowoff + __umul24(pcol, (unsigned)Dp) + lane_off;
-        }
-    };
-    auto fetch = [&](CensusVec<DPL>& cv, unsigned& cl, int& g) {
-        load_census<DPL>(fr.census_r + ((long long)p - back), cv);
-        cl = fr.census_l[p];
-        g = fr.img[p];
-    };
-
-    // a diagonal line of a row tile: replay the walk from the frame edge up to the pixel before the tile (cheap
-    // register arithmetic; it reproduces the tracker state exactly, early wraps included)
-    if (KIND == AGG_D)
-        for (int i = 0; i + 1 < skip; ++i) advance();
-
-    us2 Lp[NP];
-    unsigned min_prev;
-    int g_prev;
-    if (import_state) {
-        // ---- state of the previous pixel: its L_r from the plane, its grey value, min over d ----
-        CellVec<DPL> c0;
-        load_cells<DPL>(plane + off, c0);
-        g_prev = fr.img[p];
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const unsigned w = c0.w[j >> 1];
-            Lp[j] = as_p(__builtin_amdgcn_perm(w, w, (j & 1) ? 0x0c030c02u : 0x0c010c00u));   // bytes -> u16 pairs
-        }
-        us2 m = Lp[0];
-#pragma unroll
-        for (int j = 1; j < NP; ++j) m = pk_min(m, Lp[j]);
-        min_prev = row_allmin<LPP>(min(as_u(m) & 0xFFFFu, as_u(m) >> 16));
-    } else {
-        // ---- first pixel of the line: L = C (ref :266-275) ----
-        CensusVec<DPL> cv;
-        unsigned cl;
-        fetch(cv, cl, g_prev);
-        const int lim = x - lim_bias;
-        census_costs<DPL>(cl, cv, lim, true, Lp);
-        if (PAD) {
-#pragma unroll
-            for (int j = 0; j < NP; ++j) Lp[j] = as_p(as_u(Lp[j]) | as_u(padmask[j]));
-        }
-        us2 m = Lp[0];
-#pragma unroll
-        for (int j = 1; j < NP; ++j) m = pk_min(m, Lp[j]);
-        min_prev = row_allmin<LPP>(min(as_u(m) & 0xFFFFu, as_u(m) >> 16));
-        if (store_ok) {
-            CellVec<DPL> o;
-            pack_cells<DPL>(Lp, o);
-            store_cells<DPL>(plane + off, o);
-        }
-    }
-
-    // ---- prefetch ring: census-right words, census-left word, grey value, offset, in-image limit ----
-    CensusVec<DPL> cb[PF];
-    unsigned clb[PF];
-    int gb[PF], limb[PF];
-    unsigned ob[PF];
-#pragma unroll
-    for (int u = 0; u < PF; ++u) {
-        gb[u] = 0; ob[u] = off; clb[u] = 0; limb[u] = 0;
-#pragma unroll
-        for (int i = 0; i < DPL; ++i) cb[u].r[i] = 0;
-        if (1 + u <= nsteps) {
-            advance();
-            ob[u] = off;
-            limb[u] = x - lim_bias;
-            fetch(cb[u], clb[u], gb[u]);
-        }
-    }
-    const us2 p1v = splat((unsigned)a.p1);
-
-    // one step on ring slot u; `refill` = also fetch step k + PF into the slot
-    auto step = [&](int u, bool refill) {
-        const int g = gb[u];
-        const int lim = limb[u];
-        const unsigned o = ob[u];
-        us2 C[NP];
-        census_costs<DPL>(clb[u], cb[u], lim, __any(lim < DPL - 1) != 0, C);   // consume the slot, then refill it
-        if (refill) {
-            advance();
-            ob[u] = off;
-            limb[u] = x - lim_bias;
-            fetch(cb[u], clb[u], gb[u]);
-        }
-        const int dg = g > g_prev ? g - g_prev : g_prev - g;
-        CellVec<DPL> packed;
-        min_prev = agg_step<DPL, PAD, LPP>(C, Lp, min_prev, lut_s[dg], p1v, padmask, first_lane, last_lane, packed);
-        g_prev = g;
-        if (store_ok) store_cells<DPL>(plane + o, packed);
-    };
-    // hot loop: all PF steps and all PF refills are in range, no per-step conditions
-    int k0 = 1;
-    for (; k0 + 2 * PF - 1 <= nsteps; k0 += PF) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u) step(u, true);
-    }
-    // tail: at most 2*PF-1 steps
-    for (; k0 <= nsteps; k0 += PF) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u)
-            if (k0 + u <= nsteps) step(u, k0 + u + PF <= nsteps);
-    }
-}
-
-// The anomalous line of a diagonal direction: walked with the reference's full state
-// machine incl. the out-of-image end (Q6); its L_r go to the extras rows (the pixels it visits are
-// also visited by regular lines), and it zeroes the cells no line visits (W >= H: the track it
-// should have taken).  One wave per diagonal direction; all four DPP rows compute the same line,
-// row 0 stores.
-template <int DPL, bool PAD, int LPP>
-static __device__ __forceinline__ void agg_anomalous(const AggArgs& a, const AggFrame& fr, const unsigned short* lut_s,
-                                                     int dir)
-{
-    constexpr int NP = DPL / 2;
-    constexpr int NW = (DPL + 3) / 4;
-    const int lane = threadIdx.x;
-    const int dx = a.dx[dir], dy = a.dy[dir];
-    const int W = a.W, H = a.H, Dp = a.Dp;
-    const bool fwd = (dx == 1 && dy == 1) || (dx == -1 && dy == 1);
-    const int s = fwd ? 1 : -1;
-    const int diag_step = s * (W + ((dx == dy) ? 1 : -1));                 // ref :311-322
-    const int col_step = (dx == dy) ? s : -s;
-    const int nsteps = H - 1;
-    const long long npx = (long long)W * H;
-    const int line = a.anom_line[dir];
-    const int slot = dir - 4;
-    const bool store_ok = lane < LPP;
-    const int sub = lane & (LPP - 1);
-    const bool first_lane = (sub == 0), last_lane = (sub == LPP - 1);
-    const unsigned lane_off = (unsigned)(sub * DPL);
-    uint8_t* const plane = fr.planes + (size_t)dir * a.plane_bytes;
-    uint8_t* const extras = fr.extras + (size_t)slot * H * Dp + lane_off;
-
-    us2 padmask[NP];
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        const unsigned lo = ((int)lane_off + 2 * j >= a.D) ? 0x00FFu : 0u;
-        const unsigned hi = ((int)lane_off + 2 * j + 1 >= a.D) ? 0x00FF0000u : 0u;
-        padmask[j] = as_p(lo | hi);
-    }
-    auto ghost_zero = [&](int k) {
-        if (store_ok && a.ghost_zero) {
-            int gc = line + dx * k;
-            if (gc >= W) gc -= W;
-            if (gc < 0) gc += W;
-            const int gr = fwd ? k : H - 1 - k;
-            CellVec<DPL> z;
-#pragma unroll
-            for (int i = 0; i < NW; ++i) z.w[i] = 0;
-            store_cells<DPL>(plane + ((size_t)gr * W + gc) * Dp + lane_off, z);
-        }
-    };
-
-    long long p = (fwd ? 0 : (long long)(H - 1) * W) + line;
-    int row = fwd ? 0 : H - 1, col = line;
-    us2 Lp[NP];
-    unsigned min_prev;
-    int g_prev;
-    const int back = a.dmin + (int)lane_off + DPL - 1;
-    const int lim_bias = a.dmin + (int)lane_off;
-    {
-        CensusVec<DPL> cv;
-        load_census<DPL>(fr.census_r + (p - back), cv);
-        g_prev = fr.img[p];
-        census_costs<DPL>(fr.census_l[p], cv, (int)(p % W) - lim_bias, true, Lp);
-        if (PAD) {
-#pragma unroll
-            for (int j = 0; j < NP; ++j) Lp[j] = as_p(as_u(Lp[j]) | as_u(padmask[j]));
-        }
-        us2 m = Lp[0];
-#pragma unroll
-        for (int j = 1; j < NP; ++j) m = pk_min(m, Lp[j]);
-        min_prev = row_allmin<LPP>(min(as_u(m) & 0xFFFFu, as_u(m) >> 16));
-        if (store_ok) {
-            CellVec<DPL> o;
-            pack_cells<DPL>(Lp, o);
-            store_cells<DPL>(extras, o);
-        }
-        ghost_zero(0);
-    }
-    const us2 p1v = splat((unsigned)a.p1);
-    bool dead = false;
-    for (int k = 1; k <= nsteps; ++k) {
-        if (!dead) {
-            const bool not_last = fwd ? (row < H - 1) : (row > 0);
-            if (col == W - 1 && not_last)      { p = (long long)(row + s) * W;           col = 0; }       // ref :297-303
-            else if (col == 0 && not_last)     { p = (long long)(row + s) * W + (W - 1); col = W - 1; }   // ref :304-310
-            else                               { p += diag_step; }
-            row = (row + s) & 0xFFFF;
-            col = (col + col_step) & 0xFFFF;
-            if (p < 0 || p >= npx) dead = true;                            // Q6: the line ends
-        }
-        if (!dead) {                                                       // uniform (all rows walk the same line)
-            CellVec<DPL> packed;
-            CensusVec<DPL> cv;
-            us2 C[NP];
-            load_census<DPL>(fr.census_r + (p - back), cv);
-            const int g = fr.img[p];
-            census_costs<DPL>(fr.census_l[p], cv, (int)(p % W) - lim_bias, true, C);
-            const int dg = g > g_prev ? g - g_prev : g_prev - g;
-            min_prev = agg_step<DPL, PAD, LPP>(C, Lp, min_prev, lut_s[dg], p1v, padmask, first_lane, last_lane, packed);
-            g_prev = g;
-            if (store_ok) store_cells<DPL>(extras + (size_t)k * Dp, packed);
-        }
-        ghost_zero(k);
-    }
-}
-
-template <int DPL, bool PAD, int LPP, int HL>
-__global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
-{
-    __shared__ unsigned short lut_s[256];
-    const int lane = threadIdx.x;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) lut_s[lane * 4 + i] = a.lut[lane * 4 + i];
-    __syncthreads();
-
-    // Batch: consecutive blocks are the same line group of consecutive frames, so every frame's long
-    // horizontal lines are dispatched first.  Per frame, blocks [block_begin[d], block_begin[d+1]) are the
-    // regular lines of direction d; the last blocks (one per diagonal direction) are the anomalous lines.
-    const int frame = blockIdx.x % a.B;
-    const int b = blockIdx.x / a.B;
-    AggFrame fr;
-    fr.img = a.img + (size_t)frame * a.W * a.H;
-    fr.census_l = a.census_l + (size_t)frame * a.W * a.H;
-    fr.census_r = a.census_r + (size_t)frame * a.W * a.H;
-    fr.planes = a.planes + (size_t)frame * 8 * a.plane_bytes;
-    fr.extras = a.extras + (size_t)frame * 4 * a.H * a.Dp;
-    if (b >= a.block_begin[8]) {
-        agg_anomalous<DPL, PAD, LPP>(a, fr, lut_s, 4 + (b - a.block_begin[8]));
-        return;
-    }
-    int dir = 0;
-    while (dir + 1 < a.ndirs && b >= a.block_begin[dir + 1]) ++dir;
-    const int grp = b - a.block_begin[dir];
-    // the horizontal lines are the longest serial chains of the launch (W-1 dependent steps): their waves
-    // get issue priority over the shorter vertical/diagonal ones sharing the SIMD, also across frames in flight
-    if (a.dy[dir] == 0) __builtin_amdgcn_s_setprio(3);
-    // HL (single-frame mode): the horizontal lines are the critical path of the launch (W-1 serial steps), so
-    // they get 32 lanes per pixel -- fewer disparities per lane, the shortest step -- while the vertical and
-    // diagonal lines keep the lane count that costs the fewest instructions per cell
-    if (a.dy[dir] == 0) {
-        if constexpr (HL != 0) agg_regular<DPL * LPP / HL, PAD, HL, AGG_H>(a, fr, lut_s, dir, grp);
-        else               agg_regular<DPL, PAD, LPP, AGG_H>(a, fr, lut_s, dir, grp);
-    }
-    else if (a.dx[dir] == 0) agg_regular<DPL, PAD, LPP, AGG_V>(a, fr, lut_s, dir, grp);
-    else                     agg_regular<DPL, PAD, LPP, AGG_D>(a, fr, lut_s, dir, grp);
-}
-
-template <int DPL, int LPP, int HL>
-static bool launch_aggregate_hl(const AggArgs& a, int blocks, bool pad, hipStream_t st)
-{
-    constexpr int per = (HL != 0) ? DPL * LPP / HL : DPL;                 // disparities per lane on the horizontal lines
-    constexpr bool ok = (HL == 0) || ((DPL * LPP) % HL == 0 && (per == 2 || per == 4 || per == 8 || per == 16) && HL != LPP);
-    if constexpr (ok) {
-        if (pad) hipLaunchKernelGGL((sgm_aggregate_k<DPL, true, LPP, HL>), dim3(blocks), dim3(64), 0, st, a);
-        else     hipLaunchKernelGGL((sgm_aggregate_k<DPL, false, LPP, HL>), dim3(blocks), dim3(64), 0, st, a);
-        return true;
-    }
-    return false;
-}
-template <int DPL, int LPP>
-static void launch_aggregate(const AggArgs& a, int blocks, bool pad, int hl, hipStream_t st)
-{
-    if (hl == 64 && launch_aggregate_hl<DPL, LPP, 64>(a, blocks, pad, st)) return;
-    if (hl == 32 && launch_aggregate_hl<DPL, LPP, 32>(a, blocks, pad, st)) return;
-    launch_aggregate_hl<DPL, LPP, 0>(a, blocks, pad, st);
-}
-
+// kernels for negative P1 live in sgm_aggregate_generic.hip (their own translation unit: parallel build)
+bool sgmd_aggregate_launch_generic(int lpp, int dpl, const AggArgs* a, int blocks, int pad, hipStream_t st);
 
 extern "C" {
 
@@ -543,21 +42,10 @@ int sgmd_aggregate(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* 
     blocks *= g->B;                                    // every frame of the batch in the same launch
     const bool pad = (g->D != g->Dp);
     hipStream_t st = (hipStream_t)stream;
-    // (DPL, LPP): disparities per lane x lanes per pixel = Dp.  16 lanes per pixel (4 lines per wave) gives
-    // the shortest serial step; 8 lanes per pixel (8 lines per wave) spends ~40 % fewer VALU instructions
-    // per cell and is what a batch of frames (VALU-bound) uses.
-    const int key = g->LPP * 100 + g->DPL;
-    switch (key) {
-    case 1602: launch_aggregate<2, 16>(a, blocks, pad, g->HL, st); break;
-    case 1604: launch_aggregate<4, 16>(a, blocks, pad, g->HL, st); break;
-    case 1608: launch_aggregate<8, 16>(a, blocks, pad, g->HL, st); break;
-    case 1612: launch_aggregate<12, 16>(a, blocks, pad, g->HL, st); break;
-    case 1616: launch_aggregate<16, 16>(a, blocks, pad, g->HL, st); break;
-    case 1632: launch_aggregate<32, 16>(a, blocks, pad, g->HL, st); break;
-    case 804:  launch_aggregate<4, 8>(a, blocks, pad, g->HL, st); break;
-    case 808:  launch_aggregate<8, 8>(a, blocks, pad, g->HL, st); break;
-    case 816:  launch_aggregate<16, 8>(a, blocks, pad, g->HL, st); break;
-    default:
+    bool launched;
+    if (a.p1 >= 0) launched = launch_aggregate_key<true>(g->LPP, g->DPL, a, blocks, pad, g->HL, st);
+    else           launched = sgmd_aggregate_launch_generic(g->LPP, g->DPL, &a, blocks, pad ? 1 : 0, st);
+    if (!launched) {
         fprintf(stderr, "sgm_mi355x: unsupported lanes-per-pixel/DPL combination %d/%d\n", g->LPP, g->DPL);
         return -1;
     }

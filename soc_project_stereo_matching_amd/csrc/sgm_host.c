@@ -361,7 +361,9 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
     {
         const char* e = getenv("SGM_LANES_PER_PIXEL");
         const int want = (e && *e) ? atoi(e) : (s->batch >= 2 ? 8 : 16);
-        if (want == 8 && s->g.DPL >= 2 && s->g.DPL <= 8 && s->g.DPL != 6) { s->g.LPP = 8; s->g.DPL *= 2; }
+        /* negative P1 (defined by the reference's C arithmetic, covered by the parity tests, used by nobody) runs the
+         * generic aggregation step, which only exists for 16 lanes per pixel */
+        if (want == 8 && option->p1 >= 0 && s->g.DPL >= 2 && s->g.DPL <= 8 && s->g.DPL != 6) { s->g.LPP = 8; s->g.DPL *= 2; }
     }
     /* one frame per launch: the horizontal lines (W-1 serial steps) are the longest chains of the launch -> spread each
      * pixel of those over 32 lanes (2 lines per wave).  64 lanes (SGM_HL=64, one line per wave) measures the same at
@@ -373,7 +375,7 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
         int want = (e && *e) ? atoi(e) : (s->batch == 1 ? 32 : 0);
         if (want == 64 && !ok64) want = 32;
         if (want == 32 && !ok32) want = 0;
-        if (want == s->g.LPP) want = 0;
+        if (want == s->g.LPP || option->p1 < 0) want = 0;
         s->g.HL = want;
     }
     s->g.dmin = option->min_disparity;
