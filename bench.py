@@ -3,24 +3,31 @@
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W [--mode tiles]
 
-A "step" is one pass of the hot path over ONE BATCH of --batch frames: sgm_reset + sgm_match_device (the
-device-pointer forms of the reference's SGM_Reset + SGM_Match; the Reset is part of every pass, SURVEY.md
-Q14) on frames that are already resident in HBM when the timed region starts.  Every kernel of the
-pipeline covers all frames of the batch in one launch (MI355X runs only ~4 kernels concurrently, so
-frames are batched per launch rather than spread over many streams).  All stages run (census, cost,
-8-path aggregation, WTA, LR check, speckle removal, median = the options of the reference's main.c).
-Frames are independent units, so with N GPUs every rank processes its own K batches (weak scaling,
-no data-path collective); `value` is the whole-job aggregate.
+--mode frames (default).  A "step" is one pass of the hot path over ONE BATCH of --batch frames: sgm_reset +
+sgm_match_device (the device-pointer forms of the reference's SGM_Reset + SGM_Match; the Reset is part of every pass,
+SURVEY.md Q14) on frames that are already resident in HBM when the timed region starts.  Every kernel of the pipeline
+covers all frames of the batch in one launch.  All stages run (census, cost, 8-path aggregation, WTA, LR check,
+speckle removal, median = the options of the reference's main.c).  Frames are independent units, so with N GPUs every
+rank processes its own K batches (weak scaling, no data-path collective); `value` is the whole-job aggregate.
+
+--mode tiles.  Every frame is cut into N row tiles, one per GPU (soc_project_stereo_matching_amd/tiling.py): boundary
+path costs are handed from rank to rank, several frames are in flight so that the ranks work as a pipeline, the rows are
+gathered on the frame's owner rank, which runs speckle removal + median.  A step is one frame; strong scaling.
+
+Every frame of the LAST timed batch of every in-flight instance is hashed against the digest the reference's own C
+produced for that seed (tests/golden/bench_frames.json): `frames_verified`.
 
 Headline workload = BASELINE.json configs[1]: KITTI 1242x375, D=128, 8 paths.
 Metric: Mdisp/s = W*H*D*paths*frames / t / 1e6  (BASELINE.json "metric").
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -29,14 +36,40 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WORKLOADS = {
-    # name: (W, H, D, seed, golden case whose digest pins frame 0)
-    "kitti_1242x375_d128_p8": (1242, 375, 128, 0x5EED0002, "c2_kitti_1242x375_d128"),
-    "cone_450x375_d64_p8": (450, 375, 64, 0x5EED0001, "c1_synth_450x375_d64"),
-    "middlebury_2880x1988_d256_p8": (2880, 1988, 256, 0x5EED0003, None),
-    "drivingstereo_1762x800_d192_p8": (1762, 800, 192, 0x5EED0005, None),
+    # name: (W, H, D, first seed); frame f of a rank's stream has seed first + f (digests: tests/golden/bench_frames.json)
+    "kitti_1242x375_d128_p8": (1242, 375, 128, 0x5EED0002),
+    "cone_450x375_d64_p8": (450, 375, 64, 0x5EED0001),
+    "middlebury_2880x1988_d256_p8": (2880, 1988, 256, 0x5EED0003),
+    "drivingstereo_1762x800_d192_p8": (1762, 800, 192, 0x5EED0005),
+    "uhd_3840x2160_d128_p8": (3840, 2160, 128, 0x5EED0006),
+    "uhd_3840x2160_d256_p8": (3840, 2160, 256, 0x5EED0007),
 }
-HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
+N_SIMD = 1024                  # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9               # max shader clock
+VALU_ISSUE_CYCLES = 4          # cycles one wave-level VALU instruction occupies its SIMD's issue (profiles/*valu_rate*.txt)
 PATHS = 8
+
+
+def source_id():
+    """Identifies the kernels a counter profile belongs to: sha256 over the HIP sources (first 16 hex digits)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "soc_project_stereo_matching_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            with open(os.path.join(csrc, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def golden_digests(workload):
+    path = os.path.join(ROOT, "tests", "golden", "bench_frames.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        wl = json.load(f)["workloads"].get(workload, {})
+    return {int(k): v["sha256"]["final"] for k, v in wl.get("frames", {}).items()}
 
 
 def cpu_baseline(w, h, d, seed, budget_s=25.0):
@@ -75,21 +108,141 @@ def cpu_baseline(w, h, d, seed, budget_s=25.0):
             "fps": round(1.0 / t, 4)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--batch", type=int, default=8, help="frames per step (one launch per stage covers them all)")
-    ap.add_argument("--workload", default="kitti_1242x375_d128_p8", choices=sorted(WORKLOADS))
-    ap.add_argument("--in-flight", type=int, default=2, help="instances (HIP streams) a rank round-robins batches over")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def host_boundary(S, device, w, h, d, opt, pairs, B, digests, seeds, budget_s=6.0):
+    """What a caller of the HOST-pointer boundary gets (PCIe inclusive; never `value`).
+    blocking  = the reference contract: SGM_Reset + SGM_Match per frame on pageable arrays, one frame at a time.
+    pipelined = sgm_reset + sgm_match_async on batches of B frames round-robined over 3 instances, each driven by
+                its own host thread (the staging copies of one batch overlap the kernels of the others), once with
+                pageable caller buffers (staged through pinned memory) and once with sgm_host_alloc'ed buffers."""
+    res = {}
+    # ---- blocking, one frame per call, global reference entry points
+    g = S.SGM()
+    l0, r0 = pairs[0]
+    n, t_sum, ok = 0, 0.0, True
+    t_begin = time.perf_counter()
+    while n < 200 and time.perf_counter() - t_begin < budget_s / 3:
+        l, r = pairs[n % len(pairs)]
+        t0 = time.perf_counter()
+        out = g.compute(l, r, opt)                               # sgm_compute = SGM_Reset + SGM_Match
+        dt = time.perf_counter() - t0
+        if n >= 2:
+            t_sum += dt
+        if out is None:
+            ok = False
+            break
+        n += 1
+    if ok and n > 2:
+        ms = t_sum / (n - 2) * 1e3
+        sd = seeds[(n - 1) % len(pairs)]
+        res["blocking_single_frame"] = {"ms_per_frame": round(ms, 4), "fps": round(1e3 / ms, 1), "frames": n - 2,
+                                        "entry": "sgm_compute (SGM_Reset + SGM_Match), pageable numpy arrays",
+                                        "verified": (hashlib.sha256(out.tobytes()).hexdigest() == digests[sd]) if sd in digests else None}
+    g.shutdown()
 
+    # ---- pipelined: 3 instances x batch B, one host thread each
+    for kind in ("pageable", "pinned"):
+        n_inst = 3
+        insts = [S.SGMInstance(device, batch=B) for _ in range(n_inst)]
+        bufs = []
+        for i in insts:
+            assert i.reset(w, h, opt)
+            if kind == "pinned":
+                L, R, O = i.host_array((B, h, w), np.uint8), i.host_array((B, h, w), np.uint8), i.host_array((B, h, w), np.float32)
+            else:
+                L, R, O = np.empty((B, h, w), np.uint8), np.empty((B, h, w), np.uint8), np.empty((B, h, w), np.float32)
+            for j in range(B):
+                L[j], R[j] = pairs[j % len(pairs)]
+            bufs.append((L, R, O))
+        rounds = [0] * n_inst
+        stop_at = [0.0]
+        fail = []
+
+        def worker(k):
+            i, (L, R, O) = insts[k], bufs[k]
+            while time.perf_counter() < stop_at[0]:
+                if not (i.reset(w, h, opt) and i.match_async(L, R, O) and i.match_wait()):
+                    fail.append(k)
+                    return
+                rounds[k] += 1
+
+        # warm-up round, then the timed window
+        for k in range(n_inst):
+            i, (L, R, O) = insts[k], bufs[k]
+            assert i.reset(w, h, opt) and i.match_async(L, R, O) and i.match_wait()
+        t0 = time.perf_counter()
+        stop_at[0] = t0 + budget_s / 3
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(n_inst)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        el = time.perf_counter() - t0
+        frames = sum(rounds) * B
+        ver = None
+        if not fail and all(seeds[j % len(pairs)] in digests for j in range(B)):
+            ver = all(hashlib.sha256(bufs[k][2][j].tobytes()).hexdigest() == digests[seeds[j % len(pairs)]]
+                      for k in range(n_inst) for j in range(B))
+        res[f"pipelined_{kind}"] = {"fps": round(frames / el, 1), "ms_per_frame": round(el / max(frames, 1) * 1e3, 4), "frames": frames,
+                                    "instances": n_inst, "frames_per_call": B, "host_threads": n_inst,
+                                    "entry": "sgm_reset + sgm_match_async + sgm_match_wait", "verified": ver, "failed": bool(fail)}
+        for i in insts:
+            i.close()
+    return res
+
+
+def load_counters(workload):
+    """Per-kernel hardware counters collected by tools/profile_counters.py (rocprofv3 --pmc passes), stamped with
+    the source id of the kernels they were measured on."""
+    path = os.path.join(ROOT, "profiles", "counters.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        doc = json.load(f)
+    wl = doc.get("workloads", {}).get(workload)
+    if wl is None:
+        return None
+    return {"source_id": doc.get("source_id"), "file": "profiles/counters.json", **wl}
+
+
+def kernel_roofline(kernel, ms, launches, min_ms, B, counters, alg_bytes_per_frame, alg_note, ref_equiv_bytes_per_frame=None):
+    """roofline object of one kernel: `achieved` = algorithmic bytes of THIS dataflow per launch / mean launch time
+    (HIP events over the timed region); `traffic` = HBM bytes per launch from the PMC passes; `valu` = share of the chip's
+    VALU issue slots the launch's wave-level VALU instructions take.  `bound` names the larger of the two fractions."""
+    t = ms * 1e-3
+    alg = alg_bytes_per_frame * B
+    r = {"bound": "hbm", "kernel": kernel, "achieved": round(alg / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(alg / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(ms, 4),
+         "min_launch_ms": round(min_ms, 4), "launches_timed": launches, "frames_per_launch": B,
+         "algorithmic_bytes_per_launch": int(alg), "algorithmic_bytes": alg_note}
+    if counters:
+        k = counters.get("kernels", {}).get(kernel)
+        stale = counters.get("source_id") != source_id()
+        r["counters_file"] = counters.get("file")
+        r["traffic_stale"] = stale
+        if k:
+            if k.get("hbm_bytes_per_frame") is not None:
+                r["traffic"] = int(k["hbm_bytes_per_frame"] * B)
+                r["traffic_GBps"] = round(r["traffic"] / t / 1e9, 1)
+                r["traffic_frac"] = round(r["traffic"] / t / 1e9 / HBM_PEAK_GBS, 4)
+            if k.get("valu_insts_per_frame") is not None:
+                insts = k["valu_insts_per_frame"] * B
+                vfrac = insts * VALU_ISSUE_CYCLES / (N_SIMD * CLOCK_HZ * t)
+                r["valu"] = {"wave_insts_per_launch": int(insts), "issue_cycles_per_inst": VALU_ISSUE_CYCLES,
+                             "frac": round(vfrac, 4), "of": f"{N_SIMD} SIMDs x {CLOCK_HZ / 1e9:.1f} GHz"}
+                if vfrac > (r.get("traffic_frac") or r["frac"]):
+                    r["bound"] = "valu"
+    if ref_equiv_bytes_per_frame:
+        eq = ref_equiv_bytes_per_frame * B / t / 1e9
+        r["reference_dataflow_equiv"] = {"bytes_per_launch": int(ref_equiv_bytes_per_frame * B), "GBps": round(eq, 1),
+                                         "x_peak": round(eq / HBM_PEAK_GBS, 3),
+                                         "note": "the reference dataflow's 5 B per path evaluation (SURVEY.md 8d) that this launch replaces; "
+                                                 "not a fraction of anything physical (this kernel moves ~4.5x fewer bytes)"}
+    return r
+
+
+def init_dist(args):
     import torch
     import torch.distributed as dist
-    import soc_project_stereo_matching_amd as S
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -108,8 +261,16 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
+    return world, rank, local_rank, backend
 
-    w, h, d, seed, golden = WORKLOADS[args.workload]
+
+def run_frames(args):
+    import torch
+    import torch.distributed as dist
+    import soc_project_stereo_matching_amd as S
+
+    world, rank, local_rank, backend = init_dist(args)
+    w, h, d, seed = WORKLOADS[args.workload]
     opt = S.default_option(d)
     n_inst = max(1, args.in_flight)
     B = max(1, args.batch)
@@ -119,14 +280,18 @@ def main():
             raise SystemExit("sgm_reset failed")
         i.enable_timing(True)
 
-    # synthetic batches, resident in HBM before the timed region (2 distinct batches of B distinct pairs per rank)
+    # synthetic batches, resident in HBM before the timed region: 2 distinct batches of B distinct pairs, the same on
+    # every rank (every rank can then check its results against the reference's digests)
     n_frames = 2
-    frames = []
+    frames, pairs, seeds = [], [], []
     for k in range(n_frames):
-        pairs = [S.synth_pair(w, h, d, seed + k * B + j + 4096 * rank) for j in range(B)]
-        frames.append((torch.from_numpy(np.stack([p[0] for p in pairs])).cuda(),
-                       torch.from_numpy(np.stack([p[1] for p in pairs])).cuda()))
+        ps = [S.synth_pair(w, h, d, seed + k * B + j) for j in range(B)]
+        pairs += ps
+        seeds += [seed + k * B + j for j in range(B)]
+        frames.append((torch.from_numpy(np.stack([p[0] for p in ps])).cuda(),
+                       torch.from_numpy(np.stack([p[1] for p in ps])).cuda()))
     outs = [torch.empty((B, h, w), dtype=torch.float32, device="cuda") for _ in range(n_inst)]
+    last_batch = [None] * n_inst                         # which batch an instance's output buffer holds
     torch.cuda.synchronize()
 
     def step(k):
@@ -136,6 +301,7 @@ def main():
             raise RuntimeError("sgm_reset failed")
         if not i.match_device(l.data_ptr(), r.data_ptr(), outs[k % n_inst].data_ptr()):
             raise RuntimeError("sgm_match_device failed")
+        last_batch[k % n_inst] = k % n_frames
 
     def barrier():
         if world > 1:
@@ -150,17 +316,37 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(k)
+        step(args.warmup + k)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     for i in insts:
         i.synchronize()                                  # collects the HIP-event stage times of each instance's last frame
 
+    # ---- verify what was timed: every frame of the last batch each in-flight instance produced, against the digests
+    #      of the reference's own C for those seeds (tests/golden/bench_frames.json)
+    digests = golden_digests(args.workload)
+    n_ok = n_bad = n_unpinned = 0
+    for k in range(n_inst):
+        if last_batch[k] is None:
+            continue
+        got = outs[k].cpu().numpy()
+        for j in range(B):
+            sd = seed + last_batch[k] * B + j
+            if sd not in digests:
+                n_unpinned += 1
+            elif hashlib.sha256(got[j].tobytes()).hexdigest() == digests[sd]:
+                n_ok += 1
+            else:
+                n_bad += 1
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor([elapsed, float(n_ok), float(n_bad), float(n_unpinned)], dtype=torch.float64,
+                         device="cuda" if backend == "nccl" else "cpu")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0].item())
+        n_ok, n_bad, n_unpinned = int(t[1].item()), int(t[2].item()), int(t[3].item())
 
     # per-kernel device time, mean over EVERY launch of the timed region (HIP events on the instance's own stream,
     # one event set per step; at most 64 steps per instance are kept)
@@ -173,8 +359,9 @@ def main():
             stage_min[name] = min(stage_min.get(name, 1e30), mn[name])
     stage_ms = {k: v / launches for k, v in stage_sum.items()} if launches else {}
 
-    # single-frame latency: one batch-1 instance, nothing else in flight, after the timed region
+    # single-frame latency: one batch-1 instance, nothing else in flight, after the timed region (its own output buffer)
     solo = S.SGMInstance(local_rank)
+    solo_out = torch.empty((h, w), dtype=torch.float32, device="cuda")
     lat = []
     for it in range(12):
         if it == 8:
@@ -182,65 +369,39 @@ def main():
         solo.reset(w, h, opt)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        solo.match_device(frames[0][0].data_ptr(), frames[0][1].data_ptr(), outs[0].data_ptr())
+        solo.match_device(frames[0][0].data_ptr(), frames[0][1].data_ptr(), solo_out.data_ptr())
         solo.synchronize()
         if 2 <= it < 8:
             lat.append(time.perf_counter() - t1)     # latency without the timing events
     solo_ms = solo.mean_timing()[0]
-    first_frame = outs[0][0].cpu().numpy()           # frame 0 of batch 0 = the golden case's frame
+    solo_ok = None
+    if seed in digests:
+        solo_ok = hashlib.sha256(solo_out.cpu().numpy().tobytes()).hexdigest() == digests[seed]
     solo.close()
-
-    verified = None
-    if golden is not None and rank == 0:
-        import hashlib
-        with open(os.path.join(ROOT, "tests", "golden", "cases.json")) as f:
-            want = {c["name"]: c for c in json.load(f)["cases"]}[golden]["sha256"]["final"]
-        verified = hashlib.sha256(first_frame.tobytes()).hexdigest() == want
+    for i in insts:
+        i.close()
 
     if rank == 0:
         total_frames = args.steps * B * world
         cells = w * h * d
         value = cells * PATHS * total_frames / elapsed / 1e6
         ms_per_step = elapsed / args.steps * 1e3
-        # dominant kernel = the one-launch 8-direction aggregation: 5 algorithmic bytes per path
-        # evaluation (read C 1 B + read-modify-write S 2+2 B) x W*H*D*8 per launch
-        agg_ms = stage_ms.get("aggregate")
-        agg_bytes = cells * 5 * PATHS * B               # one launch covers the B frames of a step
+        counters = load_counters(args.workload)
+        dp = -(-d // 16) * 16
+        # dominant kernel = the one-launch 8-direction aggregation.  Bytes this dataflow has to move per frame: the 8
+        # per-direction L_r planes written once (8 B per cell of the padded volume) + both census images and the left
+        # image read once (9 B per pixel).  (Reference dataflow: 5 B per path evaluation = 40 B per cell)
         roofline = None
-        if agg_ms:
-            achieved = agg_bytes / (agg_ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "sgm_aggregate_k", "achieved": round(achieved, 1),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": None, "avg_launch_ms": round(agg_ms, 4),
-                        "min_launch_ms": round(stage_min["aggregate"], 4), "launches_timed": launches,
-                        "algorithmic_bytes_per_launch": agg_bytes,
-                        "note": "priced against the reference dataflow's 5 B per path evaluation (SURVEY.md 8d); the fused "
-                                "kernel moves ~4.5x fewer bytes (traffic) and is VALU-issue bound, so frac can exceed 1"}
-            # HBM bytes of this kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, measured at
-            # one frame per launch, see profiles/hbm_traffic.json), scaled to the B frames of a launch
-            prof = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-            if os.path.exists(prof):
-                with open(prof) as f:
-                    per_frame = json.load(f).get(args.workload, {}).get("sgm_aggregate_k")
-                if per_frame:
-                    roofline["traffic"] = int(per_frame) * B
-                    # the same launch priced with the bytes it really moves (what an HBM-bound kernel would be judged by)
-                    roofline["traffic_GBps"] = round(roofline["traffic"] / (agg_ms * 1e-3) / 1e9, 1)
-                    roofline["traffic_frac"] = round(roofline["traffic_GBps"] / HBM_PEAK_GBS, 4)
-        # the other heavy kernel: cost sum + both WTAs, a pure HBM stream of the 8 planes (measured bytes, PMC)
+        if stage_ms.get("aggregate"):
+            roofline = kernel_roofline("sgm_aggregate_k", stage_ms["aggregate"], launches, stage_min["aggregate"], B, counters,
+                                       w * h * dp * 8 + w * h * 9,
+                                       "W*H*Dp*8 (eight u8 L_r planes written once) + W*H*9 (census L/R + left image read once)",
+                                       ref_equiv_bytes_per_frame=cells * 5 * PATHS)
         sum_roofline = None
-        sum_ms = stage_ms.get("sum")
-        if sum_ms and os.path.exists(os.path.join(ROOT, "profiles", "hbm_traffic.json")):
-            with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-                wl = json.load(f).get(args.workload, {})
-            fused = wl.get("per_frame_fused_sum_wta", {}).get("sgm_sum_wta_lr_k")
-            if fused and h * B >= 1024 and d <= 128:   # what the library's choice of the fused kernel needs
-                nbytes = int(fused["hbm_bytes"]) * B
-                sum_roofline = {"bound": "hbm", "kernel": "sgm_sum_wta_lr_k", "achieved": round(nbytes / (sum_ms * 1e-3) / 1e9, 1),
-                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / (sum_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                "traffic": nbytes, "avg_launch_ms": round(sum_ms, 4), "min_launch_ms": round(stage_min["sum"], 4),
-                                "note": "bytes = measured HBM traffic (8 planes read once); with a second batch in flight the "
-                                        "launch shares HBM with the other batch's aggregation"}
+        if stage_ms.get("sum") and dp <= 256:
+            sum_roofline = kernel_roofline("sgm_sum_wta_lr_k", stage_ms["sum"], launches, stage_min["sum"], B, counters,
+                                           w * h * dp * 8 + w * h * 8,
+                                           "W*H*Dp*8 (eight planes read once) + W*H*8 (two disparity maps written)")
         frame_bytes = cells * (5 * PATHS + 3)
         steps_frames = args.steps * B
         line = {
@@ -251,21 +412,37 @@ def main():
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u16 integer min-plus (f32 sub-pixel tail)", "data": "synthetic",
-            "config": {"workload": args.workload, "width": w, "height": h, "disparity_range": d, "paths": PATHS,
+            "config": {"workload": args.workload, "mode": "frames", "width": w, "height": h, "disparity_range": d, "paths": PATHS,
                        "stages": "census+cost+aggregate8+wta+lrcheck+speckle+median", "frames_per_step": B,
                        "frames_per_gpu": args.steps * B, "batches_in_flight_per_gpu": n_inst,
                        "sharding": "independent frames per rank, no collective"},
             "roofline": roofline,
             "roofline_sum_wta": sum_roofline,
-            "frame_roofline": {"algorithmic_bytes_per_frame": frame_bytes,
-                               "achieved_GBps_per_gpu": round(frame_bytes * steps_frames / elapsed / 1e9, 1),
-                               "frac_per_gpu": round(frame_bytes * steps_frames / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
+            "frame_reference_dataflow_equiv": {"bytes_per_frame": frame_bytes,
+                                               "GBps_per_gpu": round(frame_bytes * steps_frames / elapsed / 1e9, 1),
+                                               "note": "W*H*D*(5*8+3) B of the reference dataflow (SURVEY.md 8d) per frame time; not a roofline fraction"},
             "ms_per_frame": round(elapsed / steps_frames * 1e3, 4),
             "stage_ms_per_batch_launch": {k: round(v, 4) for k, v in stage_ms.items()},
             "stage_ms_single_frame": {k: round(v, 4) for k, v in solo_ms.items()},
             "single_frame_latency_ms": round(float(np.median(lat)) * 1e3, 4),
-            "verified_against_golden": verified,
+            "frames_verified": n_ok, "frames_mismatched": n_bad, "frames_without_reference_digest": n_unpinned,
+            "verified_against_golden": (n_bad == 0 and n_ok > 0 and n_unpinned == 0),
+            "verification": "sha256 of every frame of the last timed batch of each in-flight instance (all ranks) vs the "
+                            "reference's own C for the same seeds, tests/golden/bench_frames.json",
+            "single_frame_verified": solo_ok,
+            "source_id": source_id(),
         }
+        if counters and counters.get("kernels"):
+            tot = sum(v.get("hbm_bytes_per_frame") or 0 for v in counters["kernels"].values())
+            if tot:
+                line["frame_traffic"] = {"hbm_bytes_per_frame": int(tot), "GBps_per_gpu": round(tot * steps_frames / elapsed / 1e9, 1),
+                                         "frac_of_peak": round(tot * steps_frames / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+                                         "stale": counters.get("source_id") != source_id()}
+        if world == 1 and not args.no_host_boundary:
+            hb = host_boundary(S, local_rank, w, h, d, opt, pairs, B, digests, seeds)
+            for v in hb.values():
+                v["vs_device_resident"] = round(v["fps"] / line["fps"], 3)
+            line["host_boundary"] = hb
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(w, h, d, seed)
             line["cpu_baseline"] = cb
@@ -274,10 +451,31 @@ def main():
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
 
-    for i in insts:
-        i.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--mode", default="frames", choices=["frames", "tiles"])
+    ap.add_argument("--batch", type=int, default=8, help="frames per step (one launch per stage covers them all)")
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--in-flight", type=int, default=None,
+                    help="frames mode: instances (HIP streams) a rank round-robins batches over (default 2); "
+                         "tiles mode: frames in flight through the rank pipeline (default 2 x ranks)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-boundary", action="store_true")
+    args = ap.parse_args()
+    if args.mode == "tiles":
+        from soc_project_stereo_matching_amd.tile_bench import run_tiles
+        args.workload = args.workload or "uhd_3840x2160_d128_p8"
+        return run_tiles(args, init_dist, WORKLOADS, golden_digests)
+    args.workload = args.workload or "kitti_1242x375_d128_p8"
+    args.in_flight = args.in_flight or 2
+    run_frames(args)
 
 
 if __name__ == "__main__":

@@ -91,6 +91,13 @@ bool SGM_Synchronize(void);
 /* Releases every device resource of the default instance (the reference has no counterpart). */
 void SGM_Shutdown(void);
 
+/* The one-call form BASELINE.json's north_star names ("sgm_compute(left, right, params -> disparity)"; the reference
+ * itself has no such symbol, its boundary is the three functions above): SGM_Reset(width, height, option) followed by
+ * SGM_Match(img_left, img_right, disp_left) on the default instance -- the per-frame sequence of main.c:72,83 and
+ * of SURVEY.md Q14.  Host pointers, blocking, same results and the same true/false behaviour as the two calls. */
+bool sgm_compute(const uint8_t* img_left, const uint8_t* img_right, uint16_t width, uint16_t height,
+                 const SGMOption* option, float* disp_left);
+
 /* ---- explicit instances: several frames in flight on one GPU, one per HIP stream ---- */
 typedef struct sgm_instance sgm_instance;
 
@@ -102,6 +109,17 @@ bool          sgm_reset(sgm_instance* s, uint16_t width, uint16_t height, const 
 bool          sgm_match(sgm_instance* s, const uint8_t* img_left, const uint8_t* img_right, float* disp_left);
 bool          sgm_match_device(sgm_instance* s, const uint8_t* d_left, const uint8_t* d_right, float* d_disp_left);
 bool          sgm_synchronize(sgm_instance* s);
+/* Pipelined host-pointer matches (SGM_Match's H2D / kernels / D2H of SemiGlobalMatching.c:77-78,122 without the
+ * blocking wait): sgm_match_async stages the images, queues the upload, the pipeline and the download on the instance's
+ * stream and returns; the three buffers stay borrowed until sgm_match_wait (or the next sgm_match_async / sgm_reset with
+ * another shape / sgm_destroy on the same instance, which wait implicitly) has handed the result over.  A caller that
+ * round-robins frames over two or three instances overlaps the copies of one with the kernels of the others.
+ * sgm_match == sgm_match_async + sgm_match_wait.  Buffers from sgm_host_alloc (page-locked) are used in place: no
+ * staging copy on either side; any other host pointer is staged through the instance's own pinned buffers. */
+bool          sgm_match_async(sgm_instance* s, const uint8_t* img_left, const uint8_t* img_right, float* disp_left);
+bool          sgm_match_wait(sgm_instance* s);
+void*         sgm_host_alloc(sgm_instance* s, size_t bytes);   /* page-locked host memory on the instance's device; NULL on failure */
+void          sgm_host_free(sgm_instance* s, void* p);
 /* The HIP stream (hipStream_t as void*) the instance launches on, e.g. to record events. */
 void*         sgm_stream(sgm_instance* s);
 

@@ -469,10 +469,12 @@ static __device__ __forceinline__ void agg_anomalous(const AggArgs& a, const Agg
             if (gc >= W) gc -= W;
             if (gc < 0) gc += W;
             const int gr = fwd ? k : H - 1 - k;
-            CellVec<DPL> z;
+            if (gr >= a.row_begin && gr < a.row_end) {             // a row tile's planes only have storage for its own rows
+                CellVec<DPL> z;
 #pragma unroll
-            for (int i = 0; i < NW; ++i) z.w[i] = 0;
-            store_cells<DPL>(plane + ((size_t)gr * W + gc) * Dp + lane_off, z);
+                for (int i = 0; i < NW; ++i) z.w[i] = 0;
+                store_cells<DPL>(plane + ((size_t)gr * W + gc) * Dp + lane_off, z);
+            }
         }
     };
 

@@ -24,6 +24,7 @@ int   sgmd_alloc(int ordinal, void** dptr, size_t bytes);
 int   sgmd_free(int ordinal, void* dptr);
 int   sgmd_alloc_pinned(int ordinal, void** hptr, size_t bytes);
 int   sgmd_free_pinned(int ordinal, void* hptr);
+int   sgmd_host_is_pinned(int ordinal, const void* hptr, size_t bytes);   /* 1: [hptr, hptr+bytes) is page-locked HIP host memory, else 0 */
 int   sgmd_h2d_async(int ordinal, void* stream, void* dst, const void* src, size_t bytes);
 int   sgmd_d2h_async(int ordinal, void* stream, void* dst, const void* src, size_t bytes);
 int   sgmd_d2d_async(int ordinal, void* stream, void* dst, const void* src, size_t bytes);

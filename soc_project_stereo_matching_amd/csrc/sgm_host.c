@@ -60,15 +60,24 @@ struct sgm_instance {
     long n_timed;
 
     /* device buffers (capacity tracked so a Reset with the same shape allocates nothing) */
-    size_t cap_px, cap_cells, cap_extras, cap_median;
+    size_t cap_px, cap_planes, cap_S, cap_cost, cap_extras, cap_median;
+    int plane_row_lo, plane_rows;        /* image rows a direction plane has storage for: [plane_row_lo, plane_row_lo + plane_rows) --
+                                            the whole frame normally, the tile's rows + one hand-over row either side in row-tile mode */
     int cap_H, cap_row_cap;
     int tab_W, tab_H, tab_ndirs, tab_p1, tab_p2;   /* what the uploaded tables were built for */
-    void *d_left, *d_right, *d_census_l, *d_census_r, *d_census_r_alloc, *d_cost, *d_planes, *d_extras, *d_S;
+    void *d_left, *d_right, *d_census_l, *d_census_r, *d_census_r_alloc, *d_cost, *d_planes, *d_planes_alloc, *d_extras, *d_S;
+                                 /* d_planes = d_planes_alloc - plane_row_lo rows: kernels address cells by their frame
+                                    position; d_cost and d_S exist only once somebody needs them (stage read-back, Q14, D > 256) */
     void *d_disp, *d_disp_r, *d_labels, *d_sizes, *d_lut, *d_row_extras, *d_row_count;
     void *d_snap_wta, *d_snap_lr, *d_snap_speckle, *d_totals, *d_median_scratch;
     size_t plane_bytes;
     /* pinned staging for the host-pointer entry point */
     void *h_left, *h_right, *h_disp;
+    /* sgm_match_async: a match whose result has been queued on the stream and not yet handed to the caller */
+    bool async_pending;
+    float* async_out;            /* caller's buffer the staged result still has to be copied to (NULL: it was pinned, the
+                                    device wrote it directly) */
+    size_t async_bytes;
 };
 
 #define FAIL(...)                                  \
@@ -165,7 +174,8 @@ sgm_instance* sgm_create(int device)
 static void free_device_buffers(sgm_instance* s)
 {
     s->d_census_r = NULL;                                        /* points into d_census_r_alloc */
-    void** all[] = {&s->d_left, &s->d_right, &s->d_census_l, &s->d_census_r_alloc, &s->d_cost, &s->d_planes, &s->d_extras,
+    s->d_planes = NULL;                                          /* points into (or in front of) d_planes_alloc */
+    void** all[] = {&s->d_left, &s->d_right, &s->d_census_l, &s->d_census_r_alloc, &s->d_cost, &s->d_planes_alloc, &s->d_extras,
                     &s->d_S, &s->d_disp, &s->d_disp_r, &s->d_labels, &s->d_sizes, &s->d_lut, &s->d_row_extras,
                     &s->d_row_count, &s->d_snap_wta, &s->d_snap_lr, &s->d_snap_speckle, &s->d_totals,
                     &s->d_median_scratch};
@@ -177,7 +187,7 @@ static void free_device_buffers(sgm_instance* s)
     sgmd_free_pinned(s->device, s->h_right);
     sgmd_free_pinned(s->device, s->h_disp);
     s->h_left = s->h_right = s->h_disp = NULL;
-    s->cap_px = s->cap_cells = s->cap_extras = s->cap_median = 0;
+    s->cap_px = s->cap_planes = s->cap_S = s->cap_cost = s->cap_extras = s->cap_median = 0;
     s->cap_H = s->cap_row_cap = 0;
     s->tab_W = s->tab_H = 0;
 }
@@ -185,6 +195,7 @@ static void free_device_buffers(sgm_instance* s)
 void sgm_destroy(sgm_instance* s)
 {
     if (!s) return;
+    sgm_match_wait(s);
     sgmd_stream_sync(s->device, s->stream);
     free_device_buffers(s);
     sgmd_timer_destroy(s->device, s->timer);
@@ -303,47 +314,95 @@ static bool upload_tables(sgm_instance* s)
     return true;
 }
 
+/* Per-pixel buffers (sized for the whole batch) and the per-direction planes.  A plane only has storage for the rows
+ * the instance works on: every row of the frame normally; in row-tile mode the tile's rows plus the row either side that
+ * a neighbouring GPU's hand-over lands in -- 1/N of the frame, which is what lets N + 2 frames be in flight per GPU. */
 static bool ensure_buffers(sgm_instance* s)
 {
-    const size_t px = (size_t)s->g.B * s->g.W * s->g.H;          /* all frames of the batch, frame-major */
-    const size_t cells = px * (size_t)s->g.Dp;
-    if (px <= s->cap_px && cells <= s->cap_cells && s->d_S) return true;
-    sgmd_stream_sync(s->device, s->stream);
-    free_device_buffers(s);
     const int dev = s->device;
+    const size_t px = (size_t)s->g.B * s->g.W * s->g.H;          /* all frames of the batch, frame-major */
     int rc = 0;
-    rc |= sgmd_alloc(dev, &s->d_left, px);
-    rc |= sgmd_alloc(dev, &s->d_right, px);
-    rc |= sgmd_alloc(dev, &s->d_census_l, px * 4);
-    /* the aggregation kernel reads census-right up to dmin + Dp - 1 words left of a row start (masked to 127
-     * afterwards); give the buffer that much readable slack in front, sized for the largest options */
-    rc |= sgmd_alloc(dev, &s->d_census_r_alloc, CENSUS_FRONT_SLACK + px * 4);
-    if (rc == 0) s->d_census_r = (char*)s->d_census_r_alloc + CENSUS_FRONT_SLACK;
-    rc |= sgmd_alloc(dev, &s->d_cost, cells);
-    rc |= sgmd_alloc(dev, &s->d_planes, cells * 8);
-    rc |= sgmd_alloc(dev, &s->d_S, cells * 2);
-    rc |= sgmd_alloc(dev, &s->d_disp, px * 4);
-    rc |= sgmd_alloc(dev, &s->d_disp_r, px * 4);
-    rc |= sgmd_alloc(dev, &s->d_labels, px * 4);
-    rc |= sgmd_alloc(dev, &s->d_sizes, px * 4);
-    rc |= sgmd_alloc(dev, &s->d_totals, px * 4);
-    rc |= sgmd_alloc(dev, &s->d_lut, 512);
-    rc |= sgmd_alloc(dev, &s->d_snap_wta, px * 4);
-    rc |= sgmd_alloc(dev, &s->d_snap_lr, px * 4);
-    rc |= sgmd_alloc(dev, &s->d_snap_speckle, px * 4);
-    rc |= sgmd_alloc_pinned(dev, &s->h_left, px);
-    rc |= sgmd_alloc_pinned(dev, &s->h_right, px);
-    rc |= sgmd_alloc_pinned(dev, &s->h_disp, px * 4);
-    if (rc != 0) { free_device_buffers(s); FAIL("device allocation failed for %dx%dx%d", s->g.W, s->g.H, s->g.D); }
-    s->cap_px = px;
-    s->cap_cells = cells;
+    if (px > s->cap_px || !s->d_disp) {
+        sgmd_stream_sync(dev, s->stream);
+        free_device_buffers(s);
+        rc |= sgmd_alloc(dev, &s->d_left, px);
+        rc |= sgmd_alloc(dev, &s->d_right, px);
+        rc |= sgmd_alloc(dev, &s->d_census_l, px * 4);
+        /* the aggregation kernel reads census-right up to dmin + Dp - 1 words left of a row start (masked to 127
+         * afterwards); give the buffer that much readable slack in front, sized for the largest options */
+        rc |= sgmd_alloc(dev, &s->d_census_r_alloc, CENSUS_FRONT_SLACK + px * 4);
+        if (rc == 0) s->d_census_r = (char*)s->d_census_r_alloc + CENSUS_FRONT_SLACK;
+        rc |= sgmd_alloc(dev, &s->d_disp, px * 4);
+        rc |= sgmd_alloc(dev, &s->d_disp_r, px * 4);
+        rc |= sgmd_alloc(dev, &s->d_labels, px * 4);
+        rc |= sgmd_alloc(dev, &s->d_sizes, px * 4);
+        rc |= sgmd_alloc(dev, &s->d_totals, px * 4);
+        rc |= sgmd_alloc(dev, &s->d_lut, 512);
+        rc |= sgmd_alloc(dev, &s->d_snap_wta, px * 4);
+        rc |= sgmd_alloc(dev, &s->d_snap_lr, px * 4);
+        rc |= sgmd_alloc(dev, &s->d_snap_speckle, px * 4);
+        rc |= sgmd_alloc_pinned(dev, &s->h_left, px);
+        rc |= sgmd_alloc_pinned(dev, &s->h_right, px);
+        rc |= sgmd_alloc_pinned(dev, &s->h_disp, px * 4);
+        if (rc != 0) { free_device_buffers(s); FAIL("device allocation failed for %dx%dx%d", s->g.W, s->g.H, s->g.D); }
+        s->cap_px = px;
+    }
+    const bool tiled = s->tile_end != 0;
+    s->plane_row_lo = tiled && s->g.row_begin > 0 ? s->g.row_begin - 1 : 0;
+    const int row_hi = tiled && s->g.row_end < s->g.H ? s->g.row_end + 1 : s->g.H;
+    s->plane_rows = row_hi - s->plane_row_lo;
+    s->plane_bytes = (size_t)s->plane_rows * s->g.W * s->g.Dp;
+    const size_t need = (size_t)s->g.B * 8 * s->plane_bytes;
+    if (need > s->cap_planes || !s->d_planes_alloc) {
+        sgmd_stream_sync(dev, s->stream);
+        sgmd_free(dev, s->d_planes_alloc);
+        s->d_planes_alloc = NULL;
+        s->cap_planes = 0;
+        if (sgmd_alloc(dev, &s->d_planes_alloc, need) != 0)
+            FAIL("device allocation failed for the path-cost planes of %dx%dx%d (%zu bytes)", s->g.W, s->g.H, s->g.D, need);
+        s->cap_planes = need;
+    }
+    s->d_planes = (void*)((uintptr_t)s->d_planes_alloc - (uintptr_t)s->plane_row_lo * s->g.W * s->g.Dp);
     return true;
+}
+
+/* S (u16 per cell) and the cost volume (u8 per cell) are frame-sized and rarely needed: the fused kernels neither read
+ * nor write them.  They are allocated (S zero-filled) the first time something does: a Match without Reset (Q14), the
+ * separate sum / right-view kernels (D > 256, SGM_FUSED_WTA=0), sgm_keep_stages, a stage read-back. */
+static int ensure_S(sgm_instance* s)
+{
+    const size_t need = (size_t)s->g.B * s->g.W * s->g.H * s->g.Dp * 2;
+    if (s->d_S && need <= s->cap_S) return 0;
+    sgmd_stream_sync(s->device, s->stream);
+    sgmd_free(s->device, s->d_S);
+    s->d_S = NULL;
+    s->cap_S = 0;
+    int rc = sgmd_alloc(s->device, &s->d_S, need);
+    if (rc == 0) rc = sgmd_memset_async(s->device, s->stream, s->d_S, 0, need);
+    if (rc == 0) s->cap_S = need;
+    else fprintf(stderr, "sgm_mi355x: device allocation failed for the aggregated-cost volume (%zu bytes)\n", need);
+    return rc;
+}
+
+static int ensure_cost(sgm_instance* s)
+{
+    const size_t need = (size_t)s->g.B * s->g.W * s->g.H * s->g.Dp;
+    if (s->d_cost && need <= s->cap_cost) return 0;
+    sgmd_stream_sync(s->device, s->stream);
+    sgmd_free(s->device, s->d_cost);
+    s->d_cost = NULL;
+    s->cap_cost = 0;
+    const int rc = sgmd_alloc(s->device, &s->d_cost, need);
+    if (rc == 0) s->cap_cost = need;
+    else fprintf(stderr, "sgm_mi355x: device allocation failed for the cost volume (%zu bytes)\n", need);
+    return rc;
 }
 
 bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMOption* option)
 {
     if (!s || !option) return false;
     s->initialized = false;
+    if (s->async_pending && !sgm_match_wait(s)) return false;    /* its buffers may be re-sized below */
     s->opt = *option;                                            /* SemiGlobalMatching.c:41 */
     if (width == 0 || height == 0) return false;                 /* .c:43 */
     if (option->max_disparity <= option->min_disparity) return false;   /* .c:46 */
@@ -423,7 +482,6 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
         if (sgmd_alloc(s->device, &s->d_median_scratch, median_bytes) != 0) FAIL("device allocation failed (median scratch)");
         s->cap_median = median_bytes;
     }
-    s->plane_bytes = (size_t)width * height * s->g.Dp;
     /* a Reset with unchanged shape and penalties (the per-frame case, Q14) re-uploads nothing */
     if (s->tab_W != width || s->tab_H != height || s->tab_ndirs != s->paths.ndirs || s->tab_p1 != option->p1 ||
         s->tab_p2 != option->p2_init) {
@@ -463,13 +521,17 @@ static void mark(sgm_instance* s, int idx)
 static int materialize_S(sgm_instance* s)
 {
     if (!s->s_pending) return 0;
-    s->s_pending = false;
+    if (ensure_S(s) != 0) return -1;
     /* the left-view WTA this kernel also produces goes to a dead scratch map (speckle labels) */
-    return sgmd_sum_wta(s->device, s->stream, &s->g, s->paths.ndirs, s->d_planes, s->plane_bytes, s->d_extras, s->d_row_extras,
-                        s->d_row_count, s->row_cap, s->s_pending_accumulate ? 1 : 0, s->d_S, 0, 0.0f, s->d_labels);
+    const int rc = sgmd_sum_wta(s->device, s->stream, &s->g, s->paths.ndirs, s->d_planes, s->plane_bytes, s->d_extras,
+                                s->d_row_extras, s->d_row_count, s->row_cap, s->s_pending_accumulate ? 1 : 0, s->d_S, 0, 0.0f,
+                                s->d_labels);
+    if (rc == 0) s->s_pending = false;                           /* a failed launch leaves the sum pending */
+    return rc;
 }
 
-/* .c:94 (sum over the directions), .c:99 and .c:105 (both ComputeDisparity calls) */
+/* .c:94 (sum over the directions), .c:99 and .c:105 (both ComputeDisparity calls).  The Q14 bookkeeping (s_is_zero,
+ * s_pending) changes only when every launch of the stage was accepted. */
 static int sum_and_wta(sgm_instance* s, void* d_out, bool with_marks)
 {
     const SGMOption* o = &s->opt;
@@ -477,26 +539,36 @@ static int sum_and_wta(sgm_instance* s, void* d_out, bool with_marks)
     const int uniq = o->is_check_unique ? 1 : 0;
     const float keep = 1 - o->uniqueness_ratio;
     int rc;
+    if ((!s->fused_wta || accumulate || s->keep_stages) && ensure_S(s) != 0) return -1;
     if (s->fused_wta) {
         const int store = s->keep_stages ? 1 : 0;
         rc = sgmd_sum_wta_lr(s->device, s->stream, &s->g, s->paths.ndirs, s->d_planes, s->plane_bytes, s->d_extras,
                              s->d_row_extras, s->d_row_count, s->row_cap, accumulate, store, o->is_check_lr ? 1 : 0, s->d_S,
                              uniq, keep, d_out, s->d_disp_r);
+        if (rc != 0) return rc;
         s->s_pending = !store;
         s->s_pending_accumulate = accumulate != 0;
         if (with_marks) mark(s, 4);
     } else {
         rc = sgmd_sum_wta(s->device, s->stream, &s->g, s->paths.ndirs, s->d_planes, s->plane_bytes, s->d_extras,
                           s->d_row_extras, s->d_row_count, s->row_cap, accumulate, s->d_S, uniq, keep, d_out);
-        if (with_marks) mark(s, 4);
-        if (o->is_check_lr) rc |= sgmd_wta_right(s->device, s->stream, &s->g, s->d_S, uniq, keep, s->d_disp_r);
+        if (rc != 0) return rc;
+        /* d_S now holds this frame's sum whatever happens next */
         s->s_pending = false;
+        s->s_is_zero = false;
+        if (with_marks) mark(s, 4);
+        if (o->is_check_lr) rc = sgmd_wta_right(s->device, s->stream, &s->g, s->d_S, uniq, keep, s->d_disp_r);
+        if (rc != 0) return rc;
     }
     s->s_is_zero = false;
-    return rc;
+    return 0;
 }
 
-/* The body of SGM_Match (SemiGlobalMatching.c:80-122) on device buffers. */
+/* The body of SGM_Match (SemiGlobalMatching.c:80-122) on device buffers.  The first launch that is refused ends the
+ * match: nothing further is queued and false is returned with the instance in a consistent state -- d_S (or the
+ * pending planes) still describe exactly the matches that completed, so a later Match without Reset (Q14) accumulates
+ * onto the right thing. */
+#define LAUNCH(expr) do { if ((expr) != 0) goto failed; } while (0)
 static bool run_pipeline(sgm_instance* s, const void* d_left, const void* d_right, void* d_out)
 {
     const int dev = s->device;
@@ -504,40 +576,44 @@ static bool run_pipeline(sgm_instance* s, const void* d_left, const void* d_righ
     const sgmd_geom* g = &s->g;
     const SGMOption* o = &s->opt;
     const size_t px_bytes = (size_t)g->B * g->W * g->H * sizeof(float);
-    int rc = 0;
 
-    if (!s->s_is_zero) rc |= materialize_S(s);               /* Match without Reset: S of the previous frame is needed now */
+    if (!s->s_is_zero) LAUNCH(materialize_S(s));             /* Match without Reset: S of the previous frame is needed now */
     mark(s, 0);
-    rc |= sgmd_census(dev, st, g, d_left, d_right, s->d_census_l, s->d_census_r);              /* .c:82-83 */
+    LAUNCH(sgmd_census(dev, st, g, d_left, d_right, s->d_census_l, s->d_census_r));                /* .c:82-83 */
     mark(s, 1);
     /* .c:89: the cost volume is recomputed inside the aggregation kernel; it is only materialised when a
      * test wants to read it back (stage 2) */
-    if (s->keep_stages) rc |= sgmd_cost(dev, st, g, s->d_census_l, s->d_census_r, s->d_cost);
+    if (s->keep_stages) {
+        LAUNCH(ensure_cost(s));
+        LAUNCH(sgmd_cost(dev, st, g, s->d_census_l, s->d_census_r, s->d_cost));
+    }
     mark(s, 2);
     if (s->need_plane_memset && s->paths.ndirs > 4)
         for (int f = 0; f < g->B; ++f)
-            rc |= sgmd_memset_async(dev, st, (char*)s->d_planes + ((size_t)f * 8 + 4) * s->plane_bytes, 0, 4 * s->plane_bytes);
-    rc |= sgmd_aggregate(dev, st, g, &s->paths, d_left, s->d_census_l, s->d_census_r, s->d_lut, s->d_planes, s->plane_bytes,
-                         s->d_extras);                                                          /* .c:94 */
+            LAUNCH(sgmd_memset_async(dev, st, (char*)s->d_planes_alloc + ((size_t)f * 8 + 4) * s->plane_bytes, 0, 4 * s->plane_bytes));
+    LAUNCH(sgmd_aggregate(dev, st, g, &s->paths, d_left, s->d_census_l, s->d_census_r, s->d_lut, s->d_planes, s->plane_bytes,
+                          s->d_extras));                                                            /* .c:94 */
     mark(s, 3);
-    rc |= sum_and_wta(s, d_out, true);                                                          /* .c:94 sum, .c:99, .c:105 */
-    if (s->keep_stages) rc |= sgmd_d2d_async(dev, st, s->d_snap_wta, d_out, px_bytes);
+    LAUNCH(sum_and_wta(s, d_out, true));                                                            /* .c:94 sum, .c:99, .c:105 */
+    if (s->keep_stages) LAUNCH(sgmd_d2d_async(dev, st, s->d_snap_wta, d_out, px_bytes));
     mark(s, 5);
-    if (o->is_check_lr) rc |= sgmd_lrcheck(dev, st, g, d_out, s->d_disp_r, o->lrcheck_thres);   /* .c:109 */
-    if (s->keep_stages) rc |= sgmd_d2d_async(dev, st, s->d_snap_lr, d_out, px_bytes);
+    if (o->is_check_lr) LAUNCH(sgmd_lrcheck(dev, st, g, d_out, s->d_disp_r, o->lrcheck_thres));     /* .c:109 */
+    if (s->keep_stages) LAUNCH(sgmd_d2d_async(dev, st, s->d_snap_lr, d_out, px_bytes));
     mark(s, 6);
-    if (o->is_remove_speckles)                                                                  /* .c:115 */
-        rc |= sgmd_speckle(dev, st, g, d_out, 1.0f, o->min_speckle_area, s->d_labels, s->d_sizes, s->d_totals);
-    if (s->keep_stages) rc |= sgmd_d2d_async(dev, st, s->d_snap_speckle, d_out, px_bytes);
+    if (o->is_remove_speckles)                                                                      /* .c:115 */
+        LAUNCH(sgmd_speckle(dev, st, g, d_out, 1.0f, o->min_speckle_area, s->d_labels, s->d_sizes, s->d_totals));
+    if (s->keep_stages) LAUNCH(sgmd_d2d_async(dev, st, s->d_snap_speckle, d_out, px_bytes));
     mark(s, 7);
-    rc |= sgmd_median(dev, st, g, d_out, s->d_median_scratch);                                                       /* .c:120 */
+    LAUNCH(sgmd_median(dev, st, g, d_out, s->d_median_scratch));                                    /* .c:120 */
     mark(s, 8);
     if (s->timing && s->timer) {
         s->ring_next = (s->ring_next + 1) % TIMING_RING;
         if (s->ring_pending < TIMING_RING) ++s->ring_pending;      /* older sets are overwritten */
     }
-    if (rc != 0) FAIL("a kernel launch failed");
     return true;
+failed:
+    /* this match's timing set is incomplete: it is recorded over by the next match (ring_next did not advance) */
+    FAIL("a kernel launch failed; the match was abandoned");
 }
 
 /* ------------------------------------------------------------------ row tiles (one frame over several GPUs)
@@ -580,9 +656,9 @@ bool sgm_tile_begin(sgm_instance* s, const uint8_t* d_left, const uint8_t* d_rig
 {
     if (!s || !s->initialized || !d_left || !d_right) return false;
     int rc = s->s_is_zero ? 0 : materialize_S(s);
-    rc |= sgmd_census(s->device, s->stream, &s->g, d_left, d_right, s->d_census_l, s->d_census_r);
-    if (s->need_plane_memset && s->paths.ndirs > 4)
-        rc |= sgmd_memset_async(s->device, s->stream, (char*)s->d_planes + 4 * s->plane_bytes, 0, 4 * s->plane_bytes);
+    if (rc == 0) rc = sgmd_census(s->device, s->stream, &s->g, d_left, d_right, s->d_census_l, s->d_census_r);
+    if (rc == 0 && s->need_plane_memset && s->paths.ndirs > 4)
+        rc = sgmd_memset_async(s->device, s->stream, (char*)s->d_planes_alloc + 4 * s->plane_bytes, 0, 4 * s->plane_bytes);
     if (rc != 0) FAIL("a kernel launch failed");
     s->tile_left = d_left;
     int hmask = 0;
@@ -608,12 +684,12 @@ static bool boundary_copy(sgm_instance* s, int forward, void* d_buf, bool do_exp
     const size_t row_bytes = (size_t)s->g.W * s->g.Dp;
     const int mask = sweep_mask(s, forward);
     int n = 0, rc = 0;
-    for (int d = 0; d < s->paths.ndirs; ++d) {
+    for (int d = 0; d < s->paths.ndirs && rc == 0; ++d) {
         if (!((mask >> d) & 1)) continue;
         char* cell = (char*)s->d_planes + (size_t)d * s->plane_bytes + (size_t)row * row_bytes;
         char* slot = (char*)d_buf + (size_t)n++ * row_bytes;
-        rc |= do_export ? sgmd_d2d_async(s->device, s->stream, slot, cell, row_bytes)
-                        : sgmd_d2d_async(s->device, s->stream, cell, slot, row_bytes);
+        rc = do_export ? sgmd_d2d_async(s->device, s->stream, slot, cell, row_bytes)
+                       : sgmd_d2d_async(s->device, s->stream, cell, slot, row_bytes);
     }
     return rc == 0;
 }
@@ -636,7 +712,7 @@ bool sgm_tile_finish(sgm_instance* s, float* d_disp_left)
     const sgmd_geom* g = &s->g;
     const SGMOption* o = &s->opt;
     int rc = sum_and_wta(s, d_disp_left, false);
-    if (o->is_check_lr) rc |= sgmd_lrcheck(s->device, s->stream, g, d_disp_left, s->d_disp_r, o->lrcheck_thres);
+    if (rc == 0 && o->is_check_lr) rc = sgmd_lrcheck(s->device, s->stream, g, d_disp_left, s->d_disp_r, o->lrcheck_thres);
     s->tile_left = NULL;
     if (rc != 0) FAIL("a kernel launch failed");
     return true;
@@ -647,9 +723,9 @@ bool sgm_tile_post(sgm_instance* s, float* d_disp_left)
     if (!s || !s->initialized || !d_disp_left) return false;
     int rc = 0;
     if (s->opt.is_remove_speckles)
-        rc |= sgmd_speckle(s->device, s->stream, &s->g, d_disp_left, 1.0f, s->opt.min_speckle_area, s->d_labels, s->d_sizes,
-                           s->d_totals);
-    rc |= sgmd_median(s->device, s->stream, &s->g, d_disp_left, s->d_median_scratch);
+        rc = sgmd_speckle(s->device, s->stream, &s->g, d_disp_left, 1.0f, s->opt.min_speckle_area, s->d_labels, s->d_sizes,
+                          s->d_totals);
+    if (rc == 0) rc = sgmd_median(s->device, s->stream, &s->g, d_disp_left, s->d_median_scratch);
     if (rc != 0) FAIL("a kernel launch failed");
     return true;
 }
@@ -693,23 +769,60 @@ bool sgm_synchronize(sgm_instance* s)
     return true;
 }
 
-bool sgm_match(sgm_instance* s, const uint8_t* img_left, const uint8_t* img_right, float* disp_left)
+/* Hands the result of a queued sgm_match_async to its caller: waits for the stream, copies the staged disparity map
+ * to the caller's buffer (nothing to copy when that buffer was pinned: the device wrote it). */
+bool sgm_match_wait(sgm_instance* s)
+{
+    if (!s) return false;
+    if (!s->async_pending) return true;
+    s->async_pending = false;
+    if (!sgm_synchronize(s)) return false;
+    if (s->async_out) memcpy(s->async_out, s->h_disp, s->async_bytes);   /* .c:122 */
+    s->async_out = NULL;
+    return true;
+}
+
+/* The host-pointer match without the final wait: stages the images (not at all when the caller's buffers are pinned,
+ * sgm_host_alloc), queues H2D, the pipeline and D2H on the instance's stream and returns.  With a few instances
+ * round-robined by the caller, the copies of one overlap the kernels of the others (separate DMA engines). */
+bool sgm_match_async(sgm_instance* s, const uint8_t* img_left, const uint8_t* img_right, float* disp_left)
 {
     if (!s || !s->initialized) return false;                     /* .c:70 */
     if (!img_left || !img_right) return false;                   /* .c:73 */
     if (!disp_left) return false;
     if (s->tile_end != 0) FAIL("the instance is in row-tile mode (sgm_set_rows): use the sgm_tile_* sequence");
+    if (!sgm_match_wait(s)) return false;                        /* the staging buffers are free again */
     const size_t px = (size_t)s->g.B * s->g.W * s->g.H;           /* batch > 1: B consecutive frames */
-    memcpy(s->h_left, img_left, px);
-    memcpy(s->h_right, img_right, px);
-    if (sgmd_h2d_async(s->device, s->stream, s->d_left, s->h_left, px) != 0) return false;
-    if (sgmd_h2d_async(s->device, s->stream, s->d_right, s->h_right, px) != 0) return false;
-    if (!run_pipeline(s, s->d_left, s->d_right, s->d_disp)) return false;
-    if (sgmd_d2h_async(s->device, s->stream, s->h_disp, s->d_disp, px * sizeof(float)) != 0) return false;
-    if (!sgm_synchronize(s)) return false;
-    memcpy(disp_left, s->h_disp, px * sizeof(float));            /* .c:122 */
+    const void *src_l = img_left, *src_r = img_right;
+    if (!sgmd_host_is_pinned(s->device, img_left, px)) { memcpy(s->h_left, img_left, px); src_l = s->h_left; }
+    if (!sgmd_host_is_pinned(s->device, img_right, px)) { memcpy(s->h_right, img_right, px); src_r = s->h_right; }
+    const bool out_pinned = sgmd_host_is_pinned(s->device, disp_left, px * sizeof(float)) != 0;
+    bool ok = sgmd_h2d_async(s->device, s->stream, s->d_left, src_l, px) == 0 &&
+              sgmd_h2d_async(s->device, s->stream, s->d_right, src_r, px) == 0 &&
+              run_pipeline(s, s->d_left, s->d_right, s->d_disp) &&
+              sgmd_d2h_async(s->device, s->stream, out_pinned ? (void*)disp_left : s->h_disp, s->d_disp, px * sizeof(float)) == 0;
+    if (!ok) {
+        sgmd_stream_sync(s->device, s->stream);                  /* queued copies may still read the caller's / staging buffers */
+        return false;
+    }
+    s->async_pending = true;
+    s->async_out = out_pinned ? NULL : disp_left;
+    s->async_bytes = px * sizeof(float);
     return true;
 }
+
+bool sgm_match(sgm_instance* s, const uint8_t* img_left, const uint8_t* img_right, float* disp_left)
+{
+    return sgm_match_async(s, img_left, img_right, disp_left) && sgm_match_wait(s);
+}
+
+void* sgm_host_alloc(sgm_instance* s, size_t bytes)
+{
+    void* p = NULL;
+    if (!s || sgmd_alloc_pinned(s->device, &p, bytes) != 0) return NULL;
+    return p;
+}
+void sgm_host_free(sgm_instance* s, void* p) { if (s && p) sgmd_free_pinned(s->device, p); }
 
 /* ------------------------------------------------------------------ stage read-back */
 
@@ -731,6 +844,10 @@ size_t sgm_read_stage(sgm_instance* s, int which, void* host_out, size_t capacit
     const char* src = NULL;
     size_t elem = 0;
     bool volume = false;
+    int row_a = 0, row_b = s->g.H;                                /* rows the device holds of a volume stage */
+    if ((which == 2 || which == 4 || which == 6 || which == 7) && !s->keep_stages) return 0;
+    if (which == 2 && !s->d_cost) return 0;
+    if (which == 3 && (ensure_S(s) != 0 || materialize_S(s) != 0)) return 0;
     switch (which) {
     case 0: src = (const char*)s->d_census_l + f * px * 4; elem = 4; break;
     case 1: src = (const char*)s->d_census_r + f * px * 4; elem = 4; break;
@@ -743,13 +860,13 @@ size_t sgm_read_stage(sgm_instance* s, int which, void* host_out, size_t capacit
     case 8: src = (const char*)s->d_disp + f * px * 4; elem = 4; break;
     default:
         if (which >= 10 && which < 10 + s->paths.ndirs) {
+            /* frame-addressed base of the plane; only rows [plane_row_lo, plane_row_lo + plane_rows) have storage */
             src = (const char*)s->d_planes + (f * 8 + (size_t)(which - 10)) * s->plane_bytes;
             elem = 1; volume = true;
+            row_a = s->plane_row_lo; row_b = s->plane_row_lo + s->plane_rows;
         }
     }
     if (!src) return 0;
-    if ((which == 2 || which == 4 || which == 6 || which == 7) && !s->keep_stages) return 0;
-    if (which == 3 && materialize_S(s) != 0) return 0;
     const size_t need = volume ? px * s->g.D * elem : px * elem;
     if (capacity < need) return 0;
     if (sgmd_stream_sync(s->device, s->stream) != 0) return 0;
@@ -758,11 +875,13 @@ size_t sgm_read_stage(sgm_instance* s, int which, void* host_out, size_t capacit
         if (sgmd_stream_sync(s->device, s->stream) != 0) return 0;
         return need;
     }
-    const size_t padded_bytes = px * s->g.Dp * elem;
-    void* tmp = malloc(padded_bytes);
+    const size_t row_bytes = (size_t)s->g.W * s->g.Dp * elem;
+    void* tmp = calloc(px * s->g.Dp, elem);                       /* rows without storage read 0 */
     if (!tmp) return 0;
     size_t got = 0;
-    if (sgmd_d2h_async(s->device, s->stream, tmp, src, padded_bytes) == 0 && sgmd_stream_sync(s->device, s->stream) == 0)
+    if (sgmd_d2h_async(s->device, s->stream, (char*)tmp + (size_t)row_a * row_bytes, src + (size_t)row_a * row_bytes,
+                       (size_t)(row_b - row_a) * row_bytes) == 0 &&
+        sgmd_stream_sync(s->device, s->stream) == 0)
         got = compact_volume(s, tmp, elem, host_out);
     free(tmp);
     return got;
@@ -822,6 +941,13 @@ bool SGM_Match(const uint8_t* img_left, const uint8_t* img_right, float* disp_le
 {
     if (!g_default) return false;
     return sgm_match(g_default, img_left, img_right, disp_left);
+}
+
+/* north_star's one-call form: SGM_Reset + SGM_Match (SemiGlobalMatching.c:128-132, 68-125; main.c:72,83) */
+bool sgm_compute(const uint8_t* img_left, const uint8_t* img_right, uint16_t width, uint16_t height, const SGMOption* option,
+                 float* disp_left)
+{
+    return SGM_Reset(width, height, option) && SGM_Match(img_left, img_right, disp_left);
 }
 
 bool SGM_MatchDevice(const uint8_t* d_left, const uint8_t* d_right, float* d_disp_left)

@@ -12,9 +12,9 @@ static uint8_t* read_file(const char* path, size_t* n)
 {
     FILE* f = fopen(path, "rb");
     if (!f) { fprintf(stderr, "cannot open %s\n", path); return NULL; }
-    fseek(f, 0, SEEK_END);
-    long sz = ftell(f);
-    fseek(f, 0, SEEK_SET);
+    long sz = -1;
+    if (fseek(f, 0, SEEK_END) == 0) sz = ftell(f);
+    if (sz < 0 || fseek(f, 0, SEEK_SET) != 0) { fprintf(stderr, "cannot size %s (not a regular file?)\n", path); fclose(f); return NULL; }
     uint8_t* buf = (uint8_t*)malloc(sz > 0 ? (size_t)sz : 1);
     if (!buf || fread(buf, 1, (size_t)sz, f) != (size_t)sz) { fprintf(stderr, "cannot read %s\n", path); free(buf); fclose(f); return NULL; }
     fclose(f);

@@ -64,6 +64,20 @@ int sgmd_free_pinned(int ord, void* hptr)
     HIP_TRY(hipHostFree(hptr));
     return 0;
 }
+int sgmd_host_is_pinned(int ord, const void* hptr, size_t bytes)
+{
+    if (!hptr || hipSetDevice(ord) != hipSuccess) return 0;
+    const char* ends[2] = {(const char*)hptr, (const char*)hptr + (bytes ? bytes - 1 : 0)};
+    for (int i = 0; i < 2; ++i) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, ends[i]) != hipSuccess) {
+            (void)hipGetLastError();                     // an ordinary malloc'd pointer: not an error of ours
+            return 0;
+        }
+        if (at.type != hipMemoryTypeHost) return 0;
+    }
+    return 1;
+}
 int sgmd_h2d_async(int ord, void* stream, void* dst, const void* src, size_t bytes)
 {
     HIP_TRY(hipSetDevice(ord));

@@ -100,9 +100,16 @@ def load_library() -> C.CDLL:
     for f in (L.sgm_initialize, L.sgm_reset):
         f.argtypes = [C.c_void_p, C.c_uint16, C.c_uint16, opt_p]
         f.restype = C.c_bool
-    for f in (L.sgm_match, L.sgm_match_device):
+    for f in (L.sgm_match, L.sgm_match_device, L.sgm_match_async):
         f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         f.restype = C.c_bool
+    L.sgm_match_wait.argtypes = [C.c_void_p]
+    L.sgm_match_wait.restype = C.c_bool
+    L.sgm_host_alloc.argtypes = [C.c_void_p, C.c_size_t]
+    L.sgm_host_alloc.restype = C.c_void_p
+    L.sgm_host_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.sgm_compute.argtypes = [C.c_void_p, C.c_void_p, C.c_uint16, C.c_uint16, opt_p, C.c_void_p]
+    L.sgm_compute.restype = C.c_bool
     L.sgm_synchronize.argtypes = [C.c_void_p]
     L.sgm_synchronize.restype = C.c_bool
     L.sgm_stream.argtypes = [C.c_void_p]
@@ -230,6 +237,16 @@ class SGM(_StageReader):
         ok = self.lib.SGM_Match(left.ctypes.data, right.ctypes.data, out.ctypes.data)
         return out if ok else None
 
+    def compute(self, left, right, option):
+        """sgm_compute: SGM_Reset + SGM_Match in one call (north_star's entry point).  None where it returns false."""
+        left, right = _u8(left), _u8(right)
+        h, w = left.shape
+        out = np.empty((h, w), np.float32)
+        ok = self.lib.sgm_compute(left.ctypes.data, right.ctypes.data, w, h, C.byref(option), out.ctypes.data)
+        if ok:
+            self.shape = (h, w, option.max_disparity - option.min_disparity)
+        return out if ok else None
+
     def match_device(self, d_left: int, d_right: int, d_out: int) -> bool:
         return bool(self.lib.SGM_MatchDevice(d_left, d_right, d_out))
 
@@ -254,6 +271,7 @@ class SGMInstance(_StageReader):
         self.device = device
         self.shape = None
         self.batch = 1
+        self._pinned = []
         if batch != 1:
             self.set_batch(batch)
 
@@ -270,6 +288,10 @@ class SGMInstance(_StageReader):
 
     def close(self):
         if self.handle:
+            self.lib.sgm_match_wait(self.handle)
+            for p in self._pinned:
+                self.lib.sgm_host_free(self.handle, p)
+            self._pinned = []
             self.lib.sgm_destroy(self.handle)
             self.handle = None
 
@@ -318,13 +340,39 @@ class SGMInstance(_StageReader):
 
     def match(self, left, right):
         """left/right: uint8 [H][W], or [batch][H][W] when the instance has a batch > 1."""
+        if self.shape is None:
+            return None                                   # Match before Initialize: false in the reference (.c:70)
         left, right = _u8(left), _u8(right)
         want = self.shape[:2] if self.batch == 1 else (self.batch,) + tuple(self.shape[:2])
-        if self.shape is not None and tuple(left.shape) != tuple(want):
+        if tuple(left.shape) != tuple(want):
             raise ValueError(f"expected images of shape {want}, got {left.shape}")
         out = np.empty(left.shape, np.float32)
         ok = self.lib.sgm_match(self.handle, left.ctypes.data, right.ctypes.data, out.ctypes.data)
         return out if ok else None
+
+    def match_async(self, left, right, out) -> bool:
+        """sgm_match_async: queue upload + pipeline + download and return.  `left`, `right` (uint8) and `out` (float32)
+        must be C-contiguous arrays of the instance's shape that stay alive and untouched until match_wait()."""
+        for a in (left, right, out):
+            if not a.flags["C_CONTIGUOUS"]:
+                raise ValueError("match_async needs C-contiguous arrays")
+        if left.dtype != np.uint8 or right.dtype != np.uint8 or out.dtype != np.float32:
+            raise TypeError("match_async: uint8 images, float32 output")
+        return bool(self.lib.sgm_match_async(self.handle, left.ctypes.data, right.ctypes.data, out.ctypes.data))
+
+    def match_wait(self) -> bool:
+        return bool(self.lib.sgm_match_wait(self.handle))
+
+    def host_array(self, shape, dtype):
+        """A numpy array in page-locked host memory (sgm_host_alloc): sgm_match_async uses it in place, without the
+        staging copy.  Freed when the instance is closed; do not use it after that."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = self.lib.sgm_host_alloc(self.handle, n)
+        if not p:
+            raise MemoryError("sgm_host_alloc failed")
+        self._pinned.append(p)
+        buf = (C.c_uint8 * n).from_address(p)
+        return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
     def match_device(self, d_left: int, d_right: int, d_out: int) -> bool:
         """Device pointers (e.g. torch tensor .data_ptr()); asynchronous on the instance stream."""

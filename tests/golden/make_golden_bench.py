@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Digests of EVERY frame bench.py times, produced by the REFERENCE ITSELF.
+
+bench.py streams, per rank, two batches of B synthetic pairs with seeds  base + k*B + j  (k = batch, j = frame;
+rank 0) and hashes every frame of the last timed batch of each in-flight instance against the digests written
+here (`frames_verified` in the bench line).  tests/test_gpu_parity.py::test_batched_fast_path_* use the same file.
+
+    oracle/build_ref.sh 1242 375 128 && oracle/build_ref.sh 450 375 64 && oracle/build_ref.sh 1762 800 192
+    oracle/build_ref.sh 2880 1988 256 && oracle/build_ref.sh 3840 2160 256
+    python tests/golden/make_golden_bench.py [workload ...]      -> tests/golden/bench_frames.json (merged)
+
+Expected values come from oracle/_ref/libsgm_ref_<shape>.so (the reference's SemiGlobalMatching.c, guarded build,
+SURVEY.md 8c); our restatement only supplies the seeded input generator.  One process per frame (the reference
+keeps its state in globals), a few at a time (the 4K D=256 frame needs 6.4 GB of static buffers)."""
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_frames.json")
+
+# name: (W, H, D, first seed, frames)   -- the names and seeds of bench.py's WORKLOADS
+WORKLOADS = {
+    "kitti_1242x375_d128_p8": (1242, 375, 128, 0x5EED0002, 16),
+    "cone_450x375_d64_p8": (450, 375, 64, 0x5EED0001, 16),
+    "drivingstereo_1762x800_d192_p8": (1762, 800, 192, 0x5EED0005, 4),
+    "middlebury_2880x1988_d256_p8": (2880, 1988, 256, 0x5EED0003, 4),
+    "uhd_3840x2160_d128_p8": (3840, 2160, 128, 0x5EED0006, 4),
+    "uhd_3840x2160_d256_p8": (3840, 2160, 256, 0x5EED0007, 4),
+}
+KEEP = ["disp_l", "disp_r", "after_lr", "after_speckle", "final"]
+
+
+def one_frame(job):
+    name, w, h, d, seed = job
+    import resource
+    resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))   # SemiGlobalMatching.c:588-589
+    import numpy as np
+    from oracle.pyoracle import Oracle, Reference, default_option, sha
+    ref = Reference.for_shape(w, h, d)
+    assert ref is not None, f"oracle/build_ref.sh {w} {h} {d} first"
+    left, right = Oracle().synth_pair(w, h, d, seed)
+    t0 = time.time()
+    st = ref.run(left, right, default_option(d))
+    return name, seed, {"sha256": {n: sha(st[n]) for n in KEEP}, "sha256_inputs": {"left": sha(left), "right": sha(right)},
+                        "invalid_final": int(np.isinf(st["final"]).sum()), "oob_dropped": ref.oob_count(),
+                        "reference_seconds": round(time.time() - t0, 1)}
+
+
+def main():
+    names = sys.argv[1:] or list(WORKLOADS)
+    doc = {"generator": "tests/golden/make_golden_bench.py", "workloads": {}}
+    if os.path.exists(OUT):
+        with open(OUT) as f:
+            doc = json.load(f)
+    jobs = []
+    for n in names:
+        w, h, d, seed, frames = WORKLOADS[n]
+        doc["workloads"][n] = {"w": w, "h": h, "d": d, "first_seed": seed, "option": "main.c:48-65 with max_disparity = D",
+                               "frames": {}}
+        jobs += [(n, w, h, d, seed + k) for k in range(frames)]
+    jobs.sort(key=lambda j: -(j[1] * j[2] * j[3]))            # big frames first
+    procs = int(os.environ.get("GOLDEN_PROCS", "3"))
+    with mp.get_context("spawn").Pool(procs, maxtasksperchild=1) as pool:
+        for name, seed, entry in pool.imap_unordered(one_frame, jobs):
+            doc["workloads"][name]["frames"][str(seed)] = entry
+            print(name, hex(seed), entry["reference_seconds"], "s", flush=True)
+    for n in names:
+        fr = doc["workloads"][n]["frames"]
+        doc["workloads"][n]["frames"] = {k: fr[k] for k in sorted(fr, key=int)}
+    with open(OUT, "w") as f:
+        json.dump(doc, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

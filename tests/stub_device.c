@@ -1,0 +1,86 @@
+/*
+ * stub_device.c -- TEST INFRASTRUCTURE ONLY (tests/test_host_error_paths.py).
+ *
+ * A stand-in for the HIP side of csrc/sgm_device.h so that the product's C host (csrc/sgm_host.c) can be driven on a
+ * machine without a GPU: "device" memory is malloc, copies are memcpy, kernel launchers compute nothing -- they append
+ * their name (and the arguments the tests look at) to a log and can be told to refuse the n-th call.  This checks
+ * the ORDER of the stages and the error paths of the host, never results.  It is linked with sgm_host.c into a
+ * test-only library under a temporary directory; nothing of it is part of libsgm_mi355x.so.
+ */
+#include "sgm_device.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define LOG_MAX 4096
+static char g_log[LOG_MAX][40];
+static int g_log_arg[LOG_MAX];
+static int g_n;
+static char g_fail_name[40];
+static int g_fail_countdown = -1;
+
+void stub_clear(void) { g_n = 0; g_fail_countdown = -1; g_fail_name[0] = 0; }
+int stub_log_size(void) { return g_n; }
+const char* stub_log_name(int i) { return (i >= 0 && i < g_n) ? g_log[i] : ""; }
+int stub_log_arg(int i) { return (i >= 0 && i < g_n) ? g_log_arg[i] : -1; }
+/* the nth (0-based) call of launcher `name` from now on returns an error */
+void stub_fail_at(const char* name, int nth) { snprintf(g_fail_name, sizeof g_fail_name, "%s", name); g_fail_countdown = nth; }
+
+static int note(const char* name, int arg)
+{
+    if (g_n < LOG_MAX) { snprintf(g_log[g_n], sizeof g_log[g_n], "%s", name); g_log_arg[g_n] = arg; ++g_n; }
+    if (g_fail_countdown >= 0 && strcmp(name, g_fail_name) == 0 && g_fail_countdown-- == 0) {
+        g_fail_countdown = -1;
+        return 719;                                  /* some HIP error code */
+    }
+    return 0;
+}
+
+int sgmd_device_count(void) { return 1; }
+int sgmd_device_is_gfx950(int o) { (void)o; return 1; }
+int sgmd_stream_create(int o, void** st) { (void)o; *st = malloc(8); return 0; }
+int sgmd_stream_destroy(int o, void* st) { (void)o; free(st); return 0; }
+int sgmd_stream_sync(int o, void* st) { (void)o; (void)st; return note("sync", 0); }
+int sgmd_alloc(int o, void** p, size_t n)      /* logged with its size in KiB; nothing the tests do reads the bytes of a volume */
+{ (void)o; *p = calloc(1, n > (1u << 20) ? (1u << 20) : (n ? n : 16)); note("alloc", (int)(n >> 10)); return *p ? 0 : 2; }
+int sgmd_free(int o, void* p) { (void)o; free(p); return 0; }
+int sgmd_alloc_pinned(int o, void** p, size_t n) { (void)o; *p = calloc(1, n ? n : 16); return *p ? 0 : 2; }
+int sgmd_free_pinned(int o, void* p) { (void)o; free(p); return 0; }
+int sgmd_host_is_pinned(int o, const void* p, size_t n) { (void)o; (void)p; (void)n; return 0; }
+int sgmd_h2d_async(int o, void* st, void* d, const void* s, size_t n) { (void)o; (void)st; if (n <= (1u << 20)) memcpy(d, s, n); return note("h2d", (int)n); }
+int sgmd_d2h_async(int o, void* st, void* d, const void* s, size_t n) { (void)o; (void)st; if (n <= (1u << 20)) memcpy(d, s, n); return note("d2h", (int)n); }
+int sgmd_d2d_async(int o, void* st, void* d, const void* s, size_t n) { (void)o; (void)st; if (n <= (1u << 20)) memmove(d, s, n); return note("d2d", (int)n); }
+int sgmd_memset_async(int o, void* st, void* d, int v, size_t n) { (void)o; (void)st; if (n <= (1u << 20)) memset(d, v, n); return note("memset", (int)n); }
+
+int sgmd_timer_create(int o, void** t, int n) { (void)o; (void)n; *t = malloc(8); return 0; }
+void sgmd_timer_destroy(int o, void* t) { (void)o; free(t); }
+int sgmd_timer_mark(int o, void* t, void* st, int i) { (void)o; (void)t; (void)st; (void)i; return 0; }
+int sgmd_timer_elapsed(int o, void* t, int a, int b, float* ms) { (void)o; (void)t; (void)a; (void)b; *ms = 0.f; return 0; }
+
+int sgmd_census(int o, void* st, const sgmd_geom* g, const void* l, const void* r, void* cl, void* cr)
+{ (void)o; (void)st; (void)l; (void)r; (void)cl; (void)cr; return note("census", g->B); }
+int sgmd_cost(int o, void* st, const sgmd_geom* g, const void* cl, const void* cr, void* c)
+{ (void)o; (void)st; (void)g; (void)cl; (void)cr; (void)c; return note("cost", 0); }
+size_t sgmd_census_slack(const sgmd_geom* g) { return ((size_t)g->dmin + g->Dp + 8) * 4; }
+int sgmd_aggregate(int o, void* st, const sgmd_geom* g, const sgmd_paths* p, const void* img, const void* cl, const void* cr,
+                   const void* lut, void* planes, size_t pb, void* ex)
+{ (void)o; (void)st; (void)g; (void)img; (void)cl; (void)cr; (void)lut; (void)planes; (void)pb; (void)ex; return note("aggregate", p->dir_mask); }
+int sgmd_sum_wta(int o, void* st, const sgmd_geom* g, int nd, const void* pl, size_t pb, const void* ex, const void* re,
+                 const void* rc, int cap, int accumulate, void* S, int cu, float omr, void* dl)
+{ (void)o; (void)st; (void)g; (void)nd; (void)pl; (void)pb; (void)ex; (void)re; (void)rc; (void)cap; (void)S; (void)cu; (void)omr; (void)dl;
+  return note("sum_wta", accumulate); }
+int sgmd_sum_wta_lr_supported(const sgmd_geom* g, int cap) { (void)cap; return g->Dp <= 256; }
+int sgmd_sum_wta_lr(int o, void* st, const sgmd_geom* g, int nd, const void* pl, size_t pb, const void* ex, const void* re,
+                    const void* rc, int cap, int accumulate, int store_S, int do_right, void* S, int cu, float omr, void* dl, void* dr)
+{ (void)o; (void)st; (void)g; (void)nd; (void)pl; (void)pb; (void)ex; (void)re; (void)rc; (void)cap; (void)do_right; (void)S; (void)cu; (void)omr; (void)dl; (void)dr;
+  return note("sum_wta_lr", accumulate | (store_S << 1)); }
+int sgmd_wta_right(int o, void* st, const sgmd_geom* g, const void* S, int cu, float omr, void* dr)
+{ (void)o; (void)st; (void)g; (void)S; (void)cu; (void)omr; (void)dr; return note("wta_right", 0); }
+int sgmd_lrcheck(int o, void* st, const sgmd_geom* g, void* dl, const void* dr, float th)
+{ (void)o; (void)st; (void)g; (void)dl; (void)dr; (void)th; return note("lrcheck", 0); }
+int sgmd_speckle(int o, void* st, const sgmd_geom* g, void* d, float diff, unsigned area, void* a, void* b, void* c)
+{ (void)o; (void)st; (void)g; (void)d; (void)diff; (void)a; (void)b; (void)c; return note("speckle", (int)area); }
+size_t sgmd_median_scratch_bytes(const sgmd_geom* g) { return (size_t)g->W * g->H * 4; }
+int sgmd_median(int o, void* st, const sgmd_geom* g, void* d, void* s)
+{ (void)o; (void)st; (void)g; (void)d; (void)s; return note("median", 0); }

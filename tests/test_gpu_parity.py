@@ -414,3 +414,145 @@ def test_c_driver_reproduces_the_reference_fixture(tmp_path):
     assert np.argwhere(got != z["im2_d_png"]).tolist() == [[374, 153]]
     raw = np.fromfile(out_raw, np.float32).reshape(375, 450)
     assert_same(raw, load_npz("cone_final.npz")["final"], "driver raw disparities")
+
+
+def _bench_frames(workload):
+    import json
+    import os
+    from conftest import ROOT
+    path = os.path.join(ROOT, "tests", "golden", "bench_frames.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)["workloads"].get(workload)
+
+
+def test_batched_fast_path_kitti_against_reference_digests():
+    """The configuration bench.py times: batches of 8 KITTI frames, keep_stages OFF (the non-SLOW instantiation of the
+    fused cost-sum/WTA kernel, S never stored), device-resident frames, TWO instances interleaved on their own
+    streams.  Every frame's final map and right-view map against the digests the reference's own C produced for the
+    16 seeds bench.py uses (tests/golden/bench_frames.json)."""
+    import torch
+    import soc_project_stereo_matching_amd as S
+    wl = _bench_frames("kitti_1242x375_d128_p8")
+    assert wl is not None and len(wl["frames"]) >= 16
+    w, h, d, seed, B = wl["w"], wl["h"], wl["d"], wl["first_seed"], 8
+    opt = S.default_option(d)
+    insts = [S.SGMInstance(0, batch=B) for _ in range(2)]
+    ins, outs = [], []
+    for k in range(2):
+        ps = [S.synth_pair(w, h, d, seed + k * B + j) for j in range(B)]
+        for j, p in enumerate(ps):
+            e = wl["frames"][str(seed + k * B + j)]["sha256_inputs"]
+            assert sha(p[0]) == e["left"] and sha(p[1]) == e["right"]
+        ins.append((torch.from_numpy(np.stack([p[0] for p in ps])).cuda(), torch.from_numpy(np.stack([p[1] for p in ps])).cuda()))
+        outs.append(torch.empty((B, h, w), dtype=torch.float32, device="cuda"))
+    torch.cuda.synchronize()
+    for i in insts:
+        i.keep_stages(False)
+        assert i.reset(w, h, opt)
+    for rep in range(3):                                   # interleaved, several rounds in flight
+        for k in range(2):
+            assert insts[k].reset(w, h, opt)
+            assert insts[k].match_device(ins[k][0].data_ptr(), ins[k][1].data_ptr(), outs[k].data_ptr())
+    for i in insts:
+        assert i.synchronize()
+    for k in range(2):
+        got = outs[k].cpu().numpy()
+        for j in range(B):
+            e = wl["frames"][str(seed + k * B + j)]["sha256"]
+            assert sha(got[j]) == e["final"], f"batch {k} frame {j}: final"
+            insts[k].select_frame(j)
+            assert sha(insts[k].read_stage("disp_r")) == e["disp_r"], f"batch {k} frame {j}: right view"
+    for i in insts:
+        i.close()
+
+
+@pytest.mark.parametrize("shape", [(600, 140, 0, 100, 8), (333, 150, 2, 66, 8), (500, 130, 0, 192, 4), (420, 260, 0, 256, 4)])
+def test_batched_fast_path_padded_disparity_ranges(oracle, shape):
+    """The same fast path (batch, keep_stages off, two instances in flight) where D is not the padded stride (D = 100
+    in a 128-wide cell, 64 in 64 with dmin 2), and for the 192 / 256 ranges of the large BASELINE shapes; H*B >= 1024 so
+    the fused kernel runs whole rows like the bench's.  Against the oracle."""
+    import torch
+    import soc_project_stereo_matching_amd as S
+    from oracle.pyoracle import default_option
+    w, h, dmin, dmax, B = shape
+    d = dmax - dmin
+    opt = default_option(dmax, dmin, min_speckle_area=20)
+    insts = [S.SGMInstance(0, batch=B) for _ in range(2)]
+    frames = [[oracle.synth_pair(w, h, d, 0xFA57000 + 97 * k + j + w) for j in range(B)] for k in range(2)]
+    want = [[oracle.run(l, r, opt) for l, r in fr] for fr in frames]
+    ins = [(torch.from_numpy(np.stack([p[0] for p in fr])).cuda(), torch.from_numpy(np.stack([p[1] for p in fr])).cuda()) for fr in frames]
+    outs = [torch.empty((B, h, w), dtype=torch.float32, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    for rep in range(2):
+        for k in range(2):
+            insts[k].keep_stages(False)
+            assert insts[k].reset(w, h, opt)
+            assert insts[k].match_device(ins[k][0].data_ptr(), ins[k][1].data_ptr(), outs[k].data_ptr())
+    for k in range(2):
+        assert insts[k].synchronize()
+        got = outs[k].cpu().numpy()
+        for j in range(B):
+            assert_same(got[j], want[k][j]["final"], f"{shape} batch {k} frame {j}: final")
+            insts[k].select_frame(j)
+            assert_same(insts[k].read_stage("disp_r"), want[k][j]["disp_r"], f"{shape} batch {k} frame {j}: right view")
+        insts[k].close()
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_async_host_pointer_pipeline(oracle, pinned):
+    """sgm_match_async / sgm_match_wait (the pipelined host-pointer boundary): three instances round-robined, batches
+    of 2 frames, caller buffers pageable (staged) or from sgm_host_alloc (used in place); every result against the
+    oracle; a Reset to another shape with a match still pending must hand that match over first."""
+    import soc_project_stereo_matching_amd as S
+    from oracle.pyoracle import default_option
+    w, h, d, B = 320, 96, 64, 2
+    opt = default_option(d)
+    insts = [S.SGMInstance(0, batch=B) for _ in range(3)]
+    for i in insts:
+        assert i.reset(w, h, opt)
+    mk = (lambda i, shp, dt: i.host_array(shp, dt)) if pinned else (lambda i, shp, dt: np.empty(shp, dt))
+    bufs = [(mk(i, (B, h, w), np.uint8), mk(i, (B, h, w), np.uint8), mk(i, (B, h, w), np.float32)) for i in insts]
+    n_rounds = 7
+    wants, gots = {}, {}
+    for k in range(n_rounds):
+        i, (L, R, O) = insts[k % 3], bufs[k % 3]
+        if k >= 3:
+            assert i.match_wait()
+            gots[k - 3] = O.copy()
+        for j in range(B):
+            l, r = oracle.synth_pair(w, h, d, 0xA5C000 + k * B + j)
+            L[j], R[j] = l, r
+            wants[(k, j)] = oracle.run(l, r, opt)["final"]
+        assert i.reset(w, h, opt)
+        assert i.match_async(L, R, O)
+    for k in range(n_rounds - 3, n_rounds):
+        if k == n_rounds - 1:
+            assert insts[k % 3].reset(w + 8, h, opt)          # another shape: waits for and delivers the pending match
+        else:
+            assert insts[k % 3].match_wait()
+        gots[k] = bufs[k % 3][2].copy()
+    for k in range(n_rounds):
+        for j in range(B):
+            assert_same(gots[k][j], wants[(k, j)], f"round {k} frame {j}")
+    for i in insts:
+        i.close()
+
+
+def test_sgm_compute_is_reset_plus_match(gsgm, oracle):
+    """north_star's one-call entry: sgm_compute(left, right, w, h, &opt, disp) == SGM_Reset + SGM_Match; a second call
+    must not accumulate onto the first (Q14) and argument errors return false like the two calls."""
+    import ctypes as C
+    import soc_project_stereo_matching_amd as S
+    from oracle.pyoracle import default_option
+    l, r = oracle.synth_pair(200, 60, 32, 0xC0FFEE)
+    l2, r2 = oracle.synth_pair(200, 60, 32, 0xC0FFEF)
+    opt = default_option(32, min_speckle_area=10)
+    assert_same(gsgm.compute(l, r, opt), oracle.run(l, r, opt)["final"], "first")
+    assert_same(gsgm.compute(l2, r2, opt), oracle.run(l2, r2, opt)["final"], "second (reset in between)")
+    lib = S.load_library()
+    out = np.empty((60, 200), np.float32)
+    assert not lib.sgm_compute(l.ctypes.data, r.ctypes.data, 0, 60, C.byref(opt), out.ctypes.data)
+    assert not lib.sgm_compute(None, r.ctypes.data, 200, 60, C.byref(opt), out.ctypes.data)
+    assert not lib.sgm_compute(l.ctypes.data, r.ctypes.data, 200, 60, C.byref(default_option(5, 9)), out.ctypes.data)
