@@ -216,3 +216,214 @@ def match_tiled_in_process(engines, left, right):
                 engines[k].export_boundary(forward, buf)
     full = torch.cat([e.finish() for e in engines], dim=0) if n > 1 else engines[0].finish().clone()
     return engines[0].post(full.contiguous())
+
+
+# ======================================================================================================================
+# Frames in flight: the ranks as a systolic pipeline
+# ======================================================================================================================
+#
+# match_tiled above runs ONE frame at a time: while rank 0 sweeps, ranks 1..N-1 wait for its hand-over, so a frame takes
+# as long as on one GPU.  With frames in flight the same hand-overs form a pipeline: at step s rank r does
+#
+#     tile_begin            of frame s                    (census, horizontal paths of its rows, anomalous lines)
+#     forward sweep         of frame s - r                (needs the hand-over rank r-1 produced at step s-1)
+#     backward sweep        of frame s - (N-1-r)          (needs the hand-over rank r+1 produced at step s-1)
+#     tile_finish           of frame s - max(r, N-1-r)    (both sweeps of that frame are done: cost sum, WTA, LR check)
+#     speckle + median      of frame s - N, on its owner rank (s - N) mod N only (not on every rank)
+#
+# and between steps s and s+1 ONE grouped exchange per rank (torch.distributed.batch_isend_irecv: a single RCCL group,
+# so the sends and receives of neighbouring ranks cannot deadlock on each other): forward hand-over to r+1, backward
+# hand-over to r-1, and the disparity rows of frame s-(N-1) -- finished on every rank by then -- to its owner.  Every
+# rank issues the same step sequence, so each send meets its receive in the same exchange.  A frame lives in one of R
+# >= N+2 slots per rank (a slot = an SGMInstance restricted to the rank's rows, its stream, its hand-over buffers and a
+# [H][W] disparity map); nothing blocks the host: kernels of a slot are ordered by its stream, exchanges run on a
+# communication stream, and HIP events order the two (slot -> exchange -> slot).  In the steady state every rank does
+# 1/N of every stage of one frame per step; speckle + median of a frame run once, on its owner.
+
+class SlotEngine:
+    """What TilePipeline drives: `slots` independent frame contexts on this rank (see DeviceSlotEngine)."""
+    slots = 0
+
+    def begin(self, slot, left, right): raise NotImplementedError
+    def boundary(self, slot, forward, incoming): raise NotImplementedError   # preallocated hand-over tensor
+    def import_boundary(self, slot, forward): raise NotImplementedError      # from boundary(slot, forward, True)
+    def sweep(self, slot, forward): raise NotImplementedError
+    def export_boundary(self, slot, forward): raise NotImplementedError      # into boundary(slot, forward, False)
+    def finish(self, slot): raise NotImplementedError                        # rows of this rank -> frame_map(slot)[r0:r1]
+    def frame_map(self, slot): raise NotImplementedError                     # [H][W] float32 tensor of the slot
+    def post(self, slot): raise NotImplementedError                          # speckle + median on frame_map(slot), in place
+    def exchange(self, dist, ops, slots): raise NotImplementedError          # ops: [("send"|"recv", tensor, peer)]
+    def done(self, slot): return None                                        # event after the slot's last queued work
+    def drain(self): pass                                                    # host waits for everything queued
+
+
+class DeviceSlotEngine(SlotEngine):
+    """The product engine: `slots` SGMInstances of this rank's GPU, each restricted to the rank's rows (its planes hold
+    only those rows), each on its own HIP stream; a communication stream for the exchanges; HIP events in between."""
+
+    def __init__(self, device: int, width: int, height: int, option, rows: Tuple[int, int], slots: int, host_staged: bool):
+        import torch
+        from .sgm import SGMInstance
+        self.torch = torch
+        self.dev = torch.device("cuda", device)
+        self.w, self.h, self.rows, self.option, self.slots = width, height, rows, option, slots
+        self.host_staged = host_staged              # gloo moves host tensors (rehearsals on a box whose ranks share one GPU)
+        self.inst, self.stream, self.maps, self.bufs, self.keep = [], [], [], [], [None] * slots
+        for _ in range(slots):
+            i = SGMInstance(device)
+            if not (i.set_rows(*rows) and i.reset(width, height, option)):
+                raise RuntimeError("sgm_set_rows / sgm_reset failed")
+            self.inst.append(i)
+            self.stream.append(torch.cuda.ExternalStream(i.stream, device=self.dev))
+            self.maps.append(torch.empty((height, width), dtype=torch.float32, device=self.dev))
+            n = i.tile_boundary_bytes()
+            self.bufs.append({(f, inc): torch.empty(n, dtype=torch.uint8, device=self.dev) for f in (True, False) for inc in (True, False)})
+        self.comm = torch.cuda.Stream(device=self.dev)
+
+    def _ok(self, ok, what):
+        if not ok:
+            raise RuntimeError(f"{what} failed")
+
+    def begin(self, slot, left, right):
+        t = self.torch
+        ev = t.cuda.Event()
+        ev.record(t.cuda.current_stream(self.dev))                  # the images were produced on torch's stream
+        self.stream[slot].wait_event(ev)
+        i = self.inst[slot]
+        self._ok(i.reset(self.w, self.h, self.option), "sgm_reset")   # per frame (SURVEY.md Q14); allocates nothing
+        self.keep[slot] = (left, right)
+        self._ok(i.tile_begin(left.data_ptr(), right.data_ptr()), "sgm_tile_begin")
+
+    def boundary(self, slot, forward, incoming):
+        return self.bufs[slot][(forward, incoming)]
+
+    def import_boundary(self, slot, forward):
+        self._ok(self.inst[slot].tile_import_boundary(forward, self.bufs[slot][(forward, True)].data_ptr()), "sgm_tile_import_boundary")
+
+    def sweep(self, slot, forward):
+        self._ok(self.inst[slot].tile_sweep(forward), "sgm_tile_sweep")
+
+    def export_boundary(self, slot, forward):
+        self._ok(self.inst[slot].tile_export_boundary(forward, self.bufs[slot][(forward, False)].data_ptr()), "sgm_tile_export_boundary")
+
+    def finish(self, slot):
+        self._ok(self.inst[slot].tile_finish(self.maps[slot].data_ptr()), "sgm_tile_finish")
+
+    def frame_map(self, slot):
+        return self.maps[slot]
+
+    def post(self, slot):
+        self._ok(self.inst[slot].tile_post(self.maps[slot].data_ptr()), "sgm_tile_post")
+
+    def done(self, slot):
+        ev = self.torch.cuda.Event()
+        ev.record(self.stream[slot])
+        return ev
+
+    def exchange(self, dist, ops, slots):
+        """One grouped exchange.  The communication stream first waits for everything queued on the slots whose
+        buffers the operations read or overwrite; afterwards those slots' streams wait for the exchange."""
+        t = self.torch
+        if not ops:
+            return
+        for s in slots:
+            self.comm.wait_event(self.done(s))
+        if self.host_staged:
+            self.comm.synchronize()
+            staged = [(kind, (buf.cpu() if kind == "send" else t.empty(buf.shape, dtype=buf.dtype)), buf, peer) for kind, buf, peer in ops]
+            reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend if k == "send" else dist.irecv, h, p) for k, h, _, p in staged])
+            for r in reqs:
+                r.wait()
+            with t.cuda.stream(self.comm):
+                for kind, host, buf, _ in staged:
+                    if kind == "recv":
+                        buf.copy_(host)
+        else:
+            with t.cuda.stream(self.comm):
+                reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend if k == "send" else dist.irecv, b, p) for k, b, p in ops])
+                for r in reqs:
+                    r.wait()                                        # orders the communication stream, does not block the host
+        ev = t.cuda.Event()
+        ev.record(self.comm)
+        for s in slots:
+            self.stream[s].wait_event(ev)
+
+    def drain(self):
+        for s in self.stream:
+            s.synchronize()
+        self.comm.synchronize()
+
+    def close(self):
+        self.drain()
+        for i in self.inst:
+            i.close()
+
+
+class TilePipeline:
+    """The step sequence above for one rank.  run(n_frames, get_frame, on_result):
+         get_frame(f)  -> (left, right) of frame f (every rank holds the whole images);
+         on_result(f, tensor, event) is called on the OWNER rank of frame f (f mod world) once speckle + median are queued;
+         `tensor` ([H][W]) is the slot's map: valid after `event` (None = already complete) and until the slot is reused,
+         slots - world - 1 steps later -- copy or consume it before."""
+
+    def __init__(self, engine: SlotEngine, rank: int, world: int, height: int, dist=None):
+        if engine.slots < world + 2:
+            raise ValueError(f"{world} ranks need at least {world + 2} slots per rank, got {engine.slots}")
+        self.e, self.rank, self.world, self.h, self.dist = engine, rank, world, height, dist
+        self.rows = tile_rows(height, world)
+
+    def run(self, n_frames: int, get_frame, on_result=None, throttle: int = 0):
+        e, r, N, F = self.e, self.rank, self.world, n_frames
+        R = e.slots
+        slot = lambda f: f % R                                       # noqa: E731
+        valid = lambda f: 0 <= f < F                                 # noqa: E731
+        lag = max(r, N - 1 - r)
+        step_done = []
+        for s in range(F + N + 1):
+            if throttle and s >= throttle and step_done[s - throttle] is not None:
+                step_done[s - throttle].synchronize()                # bound the host's run-ahead
+            touched = set()
+            if valid(s):
+                l, rt = get_frame(s)
+                e.begin(slot(s), l, rt)
+            f, g = s - r, s - (N - 1 - r)
+            for forward, fr in ((True, f), (False, g)):
+                if not valid(fr):
+                    continue
+                first = (r == 0) if forward else (r == N - 1)
+                last = (r == N - 1) if forward else (r == 0)
+                if not first:
+                    e.import_boundary(slot(fr), forward)
+                e.sweep(slot(fr), forward)
+                if not last:
+                    e.export_boundary(slot(fr), forward)
+            if valid(s - lag):
+                e.finish(slot(s - lag))
+            p = s - N
+            if valid(p) and p % N == r:
+                e.post(slot(p))
+                if on_result is not None:
+                    on_result(p, e.frame_map(slot(p)), e.done(slot(p)))
+            # ---- the exchange between step s and s + 1 (boundary operations first, then the row gather: neighbouring
+            #      ranks list the operations between them in the same order)
+            ops = []
+            if N > 1:
+                if valid(f) and r < N - 1:
+                    ops.append(("send", e.boundary(slot(f), True, False), r + 1)); touched.add(slot(f))
+                if valid(s + 1 - r) and r > 0:
+                    ops.append(("recv", e.boundary(slot(s + 1 - r), True, True), r - 1)); touched.add(slot(s + 1 - r))
+                if valid(g) and r > 0:
+                    ops.append(("send", e.boundary(slot(g), False, False), r - 1)); touched.add(slot(g))
+                if valid(s + 1 - (N - 1 - r)) and r < N - 1:
+                    ops.append(("recv", e.boundary(slot(s + 1 - (N - 1 - r)), False, True), r + 1)); touched.add(slot(s + 1 - (N - 1 - r)))
+                h = s - (N - 1)
+                if valid(h):
+                    owner, m = h % N, e.frame_map(slot(h))
+                    touched.add(slot(h))
+                    if r != owner:
+                        ops.append(("send", m[self.rows[r][0]:self.rows[r][1]], owner))
+                    else:
+                        ops += [("recv", m[self.rows[k][0]:self.rows[k][1]], k) for k in range(N) if k != r]
+                e.exchange(self.dist, ops, sorted(touched))
+            step_done.append(e.done(slot(s)) if throttle else None)
+        e.drain()

@@ -166,3 +166,89 @@ def test_three_ranks_over_a_process_group(tmp_path, oracle):
     for k in range(2):
         l, r = oracle.synth_pair(w, h, d, seed + k)
         assert_same(np.load(out + f".{k}.npy"), oracle.run(l, r, default_option(d))["final"], f"frame {k}")
+
+
+def test_match_tiled_with_one_rank_returns_its_own_map(oracle):
+    """world == 1 through match_tiled proper (the distributed wrapper, not the in-process rehearsal): the result must
+    not alias the engine's buffer (round 1 returned a view that the next frame overwrote)."""
+    import torch
+    from oracle.pyoracle import default_option
+    from soc_project_stereo_matching_amd.tiling import DeviceTileEngine, match_tiled
+    w, h, d = 260, 90, 48
+    opt = default_option(d)
+    eng = DeviceTileEngine(0, w, h, opt, (0, h))
+    try:
+        outs, wants = [], []
+        for k in range(2):
+            l, r = oracle.synth_pair(w, h, d, 0x1AB0 + k)
+            wants.append(oracle.run(l, r, opt)["final"])
+            outs.append(match_tiled(eng, 0, 1, torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda(), h))
+        for k in range(2):
+            assert_same(outs[k].cpu().numpy(), wants[k], f"frame {k}")
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("case", [(300, 70, 48, 1, 5), (1242, 375, 128, 1, 4), (37, 61, 8, 1, 3)],
+                         ids=lambda c: f"{c[0]}x{c[1]}_d{c[2]}")
+def test_slot_pipeline_on_one_rank(oracle, case):
+    """TilePipeline + DeviceSlotEngine with one rank: slots on their own streams, events instead of host syncs, result
+    delivered through on_result with an event.  Every frame against the oracle."""
+    import torch
+    from oracle.pyoracle import default_option
+    from soc_project_stereo_matching_amd.tiling import DeviceSlotEngine, TilePipeline
+    w, h, d, world, n = case
+    opt = default_option(d, min_speckle_area=20)
+    frames = [oracle.synth_pair(w, h, d, 0x51D0 + k) for k in range(n)]
+    dev = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in frames]
+    eng = DeviceSlotEngine(0, w, h, opt, (0, h), world + 2, host_staged=False)
+    got = {}
+
+    def on_result(f, t, ev):
+        ev.synchronize()
+        got[f] = t.cpu().numpy().copy()
+
+    try:
+        TilePipeline(eng, 0, 1, h).run(n, lambda f: dev[f], on_result)
+        for k in range(n):
+            assert_same(got[k], oracle.run(frames[k][0], frames[k][1], opt)["final"], f"frame {k}")
+    finally:
+        eng.close()
+
+
+def _pipe_rank_main(rank, world, port, w, h, d, seed, n_frames, out_path):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import soc_project_stereo_matching_amd as S
+    from soc_project_stereo_matching_amd.tiling import DeviceSlotEngine, TilePipeline, tile_rows
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    opt = S.default_option(d)
+    eng = DeviceSlotEngine(0, w, h, opt, tile_rows(h, world)[rank], world + 2, host_staged=True)   # every rank on the box's one GPU
+    pairs = [S.synth_pair(w, h, d, seed + k) for k in range(n_frames)]
+    dev = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in pairs]
+
+    def on_result(f, t, ev):
+        ev.synchronize()
+        np.save(out_path + f".{f}.npy", t.cpu().numpy())
+
+    TilePipeline(eng, rank, world, h, dist=dist).run(n_frames, lambda f: dev[f], on_result)
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+
+
+def test_three_rank_pipeline_with_frames_in_flight(tmp_path, oracle):
+    """The systolic schedule end to end with the device engine: three processes (sharing this box's one GPU), five
+    frames in flight, grouped exchanges over a gloo group (host-staged); on a multi-GPU node the same code runs with
+    backend nccl (= RCCL).  Frames complete on their owner ranks (frame f on rank f mod 3)."""
+    import torch.multiprocessing as mp
+    from oracle.pyoracle import default_option
+    w, h, d, seed, world, n = 300, 70, 48, 0xF1F0, 3, 5
+    out = str(tmp_path / "pipe")
+    mp.spawn(_pipe_rank_main, args=(world, _free_port(), w, h, d, seed, n, out), nprocs=world, join=True)
+    for k in range(n):
+        l, r = oracle.synth_pair(w, h, d, seed + k)
+        assert_same(np.load(out + f".{k}.npy"), oracle.run(l, r, default_option(d))["final"], f"frame {k}")

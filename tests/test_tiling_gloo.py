@@ -134,3 +134,125 @@ def test_tiled_schedule_over_gloo_equals_one_tile(tmp_path, world):
         engines = [ToyEngine(h, w, rows) for rows in tile_rows(h, world)]
         again = match_tiled_in_process(engines, torch.from_numpy(l) + frame, torch.from_numpy(r)).numpy()
         assert np.array_equal(again, want)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Frames in flight: TilePipeline (the systolic schedule) with a toy slot engine over gloo
+# ---------------------------------------------------------------------------------------------------------------------
+
+class ToySlotEngine:
+    """`slots` ToyEngines behind the SlotEngine interface; the exchange is a plain gloo batch_isend_irecv.  Every call
+    is recorded so the test can check the schedule (who posts what, at which step)."""
+
+    def __init__(self, h, w, rows, slots):
+        import torch
+        self.torch, self.h, self.w, self.rows, self.slots = torch, h, w, rows, slots
+        self.eng = [ToyEngine(h, w, rows) for _ in range(slots)]
+        self.maps = [torch.zeros((h, w), dtype=torch.float32) for _ in range(slots)]
+        self.bufs = [{(f, inc): self.eng[0].new_boundary() for f in (True, False) for inc in (True, False)} for _ in range(slots)]
+        self.log = []
+        self.exchanges = 0
+
+    def begin(self, slot, left, right):
+        self.eng[slot].begin(left, right)
+        self.maps[slot].fill_(-7)                                     # stale rows must never survive into a result
+        self.log.append(("begin", slot))
+
+    def boundary(self, slot, forward, incoming):
+        return self.bufs[slot][(forward, incoming)]
+
+    def import_boundary(self, slot, forward):
+        self.eng[slot].import_boundary(forward, self.bufs[slot][(forward, True)])
+
+    def sweep(self, slot, forward):
+        self.eng[slot].sweep(forward)
+
+    def export_boundary(self, slot, forward):
+        self.eng[slot].export_boundary(forward, self.bufs[slot][(forward, False)])
+
+    def finish(self, slot):
+        r0, r1 = self.rows
+        self.maps[slot][r0:r1] = self.eng[slot].finish()
+
+    def frame_map(self, slot):
+        return self.maps[slot]
+
+    def post(self, slot):
+        assert (self.maps[slot] != -7).all(), "a row of another rank never arrived"
+        self.maps[slot] += 1
+        self.log.append(("post", slot))
+
+    def exchange(self, dist, ops, slots):
+        if not ops:
+            return
+        self.exchanges += 1
+        reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend if k == "send" else dist.irecv, t, p) for k, t, p in ops])
+        for r in reqs:
+            r.wait()
+
+    def done(self, slot):
+        return None
+
+    def drain(self):
+        pass
+
+
+def _pipe_worker(rank, world, port, h, w, n_frames, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from soc_project_stereo_matching_amd.tiling import TilePipeline, tile_rows
+    from test_tiling_gloo import ToySlotEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    l, r = _images(h, w)
+    eng = ToySlotEngine(h, w, tile_rows(h, world)[rank], world + 2)
+    pipe = TilePipeline(eng, rank, world, h, dist=dist)
+    got = {}
+    for rep in range(2):                                            # the pipeline object is reusable
+        pipe.run(n_frames, lambda f: (torch.from_numpy(l) + f, torch.from_numpy(r)),
+                 lambda f, t, ev: got.__setitem__((rep, f), t.clone()))
+    for (rep, f), t in got.items():
+        assert f % world == rank                                    # only a frame's owner runs its post pass
+        np.save(f"{out_path}.rep{rep}.f{f}.npy", t.numpy())
+    assert sum(1 for e in eng.log if e[0] == "post") == 2 * len(range(rank, n_frames, world))
+    assert eng.exchanges <= 2 * (n_frames + world + 1)              # one grouped exchange per step
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_frames", [(2, 5), (3, 7), (3, 1), (4, 2)])
+def test_frames_in_flight_pipeline_over_gloo(tmp_path, world, n_frames):
+    """The systolic schedule: rank r sweeps frame s-r forward and frame s-(N-1-r) backward at step s, one grouped
+    exchange per step, the owner of a frame (f mod N) gathers its rows and runs the post pass.  Every frame -- also
+    when there are fewer frames than ranks, and across two runs of the same pipeline -- equals the one-tile result."""
+    import torch
+    import torch.multiprocessing as mp
+    from soc_project_stereo_matching_amd.tiling import match_tiled
+    h, w = 23, 17
+    out = str(tmp_path / "p")
+    mp.spawn(_pipe_worker, args=(world, _free_port(), h, w, n_frames, out), nprocs=world, join=True)
+    l, r = _images(h, w)
+    for f in range(n_frames):
+        want = match_tiled(ToyEngine(h, w, (0, h)), 0, 1, torch.from_numpy(l) + f, torch.from_numpy(r), h).numpy()
+        for rep in range(2):
+            assert np.array_equal(np.load(f"{out}.rep{rep}.f{f}.npy"), want), (rep, f)
+
+
+def test_pipeline_single_rank_and_slot_guard():
+    import torch
+    from soc_project_stereo_matching_amd.tiling import TilePipeline, match_tiled
+    h, w = 19, 11
+    l, r = _images(h, w)
+    with pytest.raises(ValueError):
+        TilePipeline(ToySlotEngine(h, w, (0, h), 2), 0, 1, h)       # needs world + 2 slots
+    eng = ToySlotEngine(h, w, (0, h), 3)
+    got = {}
+    TilePipeline(eng, 0, 1, h).run(4, lambda f: (torch.from_numpy(l) + f, torch.from_numpy(r)),
+                                   lambda f, t, ev: got.__setitem__(f, t.clone()))
+    assert sorted(got) == [0, 1, 2, 3]
+    for f in range(4):
+        want = match_tiled(ToyEngine(h, w, (0, h)), 0, 1, torch.from_numpy(l) + f, torch.from_numpy(r), h)
+        assert torch.equal(got[f], want)
