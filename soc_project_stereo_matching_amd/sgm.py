@@ -58,7 +58,8 @@ def default_option(max_disparity=64, min_disparity=0, **kw) -> SGMOption:
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "libsgm_mi355x.so")
+    """The in-tree library; SGM_LIBRARY_PATH points experiments (tools/sweep_sched.sh) at another build of it."""
+    return os.environ.get("SGM_LIBRARY_PATH") or os.path.join(_HERE, "libsgm_mi355x.so")
 
 
 def load_library() -> C.CDLL:
