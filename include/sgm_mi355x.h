@@ -83,6 +83,19 @@ bool SGM_SetDevice(int device_ordinal);
  * Takes effect at the next SGM_Initialize / SGM_Reset. */
 void SGM_SetHonorNumPaths(int honor);
 
+/* Two options the reference does not have.  Neither is pinned by the reference: the CPU oracle
+ * (oracle/sgm_oracle.c) defines them, "parity unpinned by the reference".  Both take effect at the next SGM_Initialize /
+ * SGM_Reset; the defaults are the reference's behaviour.
+ *   census window: any odd width x height of at most 64 pixels (e.g. 7x7, 9x7) instead of SemiGlobalMatching.c:134-159's
+ *     5x5 -- same bit order (raster, first comparison in the highest bit, centre included), border of width/2 columns
+ *     and height/2 rows zero, off-image cost 127.  Wide windows take the materialised-cost path (u64 census words, cost
+ *     volume, volume-fed aggregation kernels): correct, but not the fused fast path of 5x5.
+ *   reference view: 1 = the result is the RIGHT image's disparity map (the right-view winner-take-all of
+ *     SemiGlobalMatching.c:395-408), validated by the mirror image of LRCheck (.c:445-470: right pixel x with disparity d
+ *     must agree with the left map at column x + d), then speckle removal and median as usual.  0 = left (reference). */
+bool SGM_SetCensusWindow(int width, int height);
+void SGM_SetReferenceView(int right);
+
 /* Same as SGM_Match but all three pointers are DEVICE pointers (HBM-resident frames) on the
  * instance's device.  Asynchronous on the instance's stream; SGM_Synchronize waits. */
 bool SGM_MatchDevice(const uint8_t* d_left, const uint8_t* d_right, float* d_disp_left);
@@ -104,6 +117,8 @@ typedef struct sgm_instance sgm_instance;
 sgm_instance* sgm_create(int device_ordinal);                 /* NULL on failure */
 void          sgm_destroy(sgm_instance* s);
 void          sgm_set_honor_num_paths(sgm_instance* s, int honor);
+bool          sgm_set_census_window(sgm_instance* s, int width, int height);   /* see SGM_SetCensusWindow */
+void          sgm_set_reference_view(sgm_instance* s, int right);              /* see SGM_SetReferenceView */
 bool          sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMOption* option);
 bool          sgm_reset(sgm_instance* s, uint16_t width, uint16_t height, const SGMOption* option);
 bool          sgm_match(sgm_instance* s, const uint8_t* img_left, const uint8_t* img_right, float* disp_left);
@@ -157,7 +172,7 @@ bool   sgm_tile_finish(sgm_instance* s, float* d_disp_left);
 bool   sgm_tile_post(sgm_instance* s, float* d_disp_left);
 
 /* ---- stage read-back (parity tests; copies device -> host, blocking) ----
- * which: 0 census left (u32 [H][W])       1 census right (u32 [H][W])
+ * which: 0 census left (u32 [H][W])       1 census right (u32 [H][W])    (u64 words with a wide census window)
  *        2 matching cost (u8 [H][W][D])   3 aggregated cost S (u16 [H][W][D])
  *        4 left disparity after WTA       5 right-view disparity
  *        6 after LR check                 7 after speckle removal        8 final (all f32 [H][W])

@@ -87,6 +87,10 @@ class Oracle:
         L.sgmo_create.restype = C.c_void_p
         L.sgmo_destroy.argtypes = [C.c_void_p]
         L.sgmo_set_honor_num_paths.argtypes = [C.c_void_p, C.c_int]
+        L.sgmo_set_census_window.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.sgmo_set_census_window.restype = C.c_bool
+        L.sgmo_set_reference_view.argtypes = [C.c_void_p, C.c_int]
+        L.sgmo_census_window.argtypes = [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
         for f in (L.sgmo_initialize, L.sgmo_reset):
             f.argtypes = [C.c_void_p, C.c_uint16, C.c_uint16, C.POINTER(SGMOption)]
             f.restype = C.c_bool
@@ -122,6 +126,21 @@ class Oracle:
     def set_honor_num_paths(self, honor: bool):
         self.lib.sgmo_set_honor_num_paths(self.ctx, int(honor))
 
+    def set_census_window(self, cw, ch) -> bool:
+        ok = bool(self.lib.sgmo_set_census_window(self.ctx, cw, ch))
+        if ok:
+            self.wide_census = not (cw == 5 and ch == 5)
+        return ok
+
+    def set_reference_view(self, right: bool):
+        self.lib.sgmo_set_reference_view(self.ctx, int(right))
+
+    def census_window(self, img, cw, ch):
+        h, w = img.shape
+        out = np.empty((h, w), np.uint64)
+        self.lib.sgmo_census_window(np.ascontiguousarray(img).ctypes.data, w, h, cw, ch, out.ctypes.data)
+        return out
+
     def initialize(self, w, h, opt) -> bool:
         ok = self.lib.sgmo_initialize(self.ctx, w, h, C.byref(opt))
         self.shape = (h, w, opt.max_disparity - opt.min_disparity)
@@ -146,7 +165,8 @@ class Oracle:
         n = C.c_size_t()
         ptr = self.lib.sgmo_stage(self.ctx, which, C.byref(n))
         buf = (C.c_uint8 * n.value).from_address(ptr)
-        a = np.frombuffer(buf, dtype=_STAGE_DT[which]).copy()
+        dt = np.uint64 if (which < 2 and getattr(self, "wide_census", False)) else _STAGE_DT[which]
+        a = np.frombuffer(buf, dtype=dt).copy()
         h, w, d = self.shape
         return a.reshape((h, w, d) if which in (2, 3) else (h, w))
 

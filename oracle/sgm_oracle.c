@@ -34,6 +34,26 @@ void sgmo_census5x5(const uint8_t* img, int W, int H, uint32_t* census)
     }
 }
 
+/* Extension (not in the reference, which only has the 5x5 window): the same transform for any odd window of at most 64
+ * pixels -- raster order, one bit per window pixel incl. the centre (always 0), first comparison in the highest bit,
+ * border of cw/2 columns and ch/2 rows stays 0, nothing at all for W <= cw or H <= ch.  For 5x5 it equals
+ * sgmo_census5x5.  Pinned by nothing but this restatement ("parity unpinned by the reference"). */
+void sgmo_census_window(const uint8_t* img, int W, int H, int cw, int ch, uint64_t* census)
+{
+    memset(census, 0, (size_t)W * H * sizeof(uint64_t));
+    if (W <= cw || H <= ch) return;
+    const int rx = cw / 2, ry = ch / 2;
+    for (int y = ry; y < H - ry; ++y)
+        for (int x = rx; x < W - rx; ++x) {
+            const uint8_t centre = img[(size_t)y * W + x];
+            uint64_t bits = 0;
+            for (int r = -ry; r <= ry; ++r)
+                for (int c = -rx; c <= rx; ++c)
+                    bits = (bits << 1) | (uint64_t)(img[(size_t)(y + r) * W + (x + c)] < centre);
+            census[(size_t)y * W + x] = bits;
+        }
+}
+
 /* -------------------------------------------------------------------- cost */
 
 static inline uint8_t bitcount32(uint32_t v)
@@ -56,6 +76,25 @@ void sgmo_cost(const uint32_t* cl, const uint32_t* cr, int W, int H,
                 /* off-image right pixel -> UINT8_MAX/2 (ref :170-171) */
                 out[d - dmin] = (xr < 0 || xr >= W) ? (uint8_t)127
                                                     : bitcount32(a ^ cr[(size_t)y * W + xr]);
+            }
+        }
+}
+
+/* Hamming cost of 64-bit census words (extension, see sgmo_census_window); off-image = 127 as in ref :170-171 */
+void sgmo_cost64(const uint64_t* cl, const uint64_t* cr, int W, int H, int dmin, int dmax, uint8_t* cost)
+{
+    const int D = dmax - dmin;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            uint8_t* out = cost + ((size_t)y * W + x) * D;
+            const uint64_t a = cl[(size_t)y * W + x];
+            for (int d = dmin; d < dmax; ++d) {
+                const int xr = x - d;
+                if (xr < 0 || xr >= W) { out[d - dmin] = 127; continue; }
+                uint64_t v = a ^ cr[(size_t)y * W + xr];
+                uint8_t n = 0;
+                for (; v; v &= v - 1) ++n;
+                out[d - dmin] = n;
             }
         }
 }
@@ -263,6 +302,27 @@ void sgmo_lrcheck(float* dl, const float* dr, int W, int H, float thres)
         }
 }
 
+/* Extension: the RIGHT view as the reference view.  The mirror image of ref :445-470: right pixel x with disparity d
+ * corresponds to left column x + d (same float subtract->add, double rounding, truncation); invalid if that column is
+ * off the image or the left map disagrees by more than thres; kept if the left pixel is invalid. */
+void sgmo_lrcheck_right(float* dr, const float* dl, int W, int H, float thres)
+{
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            float* p = dr + (size_t)y * W + x;
+            const float d = *p;
+            if (d == INFINITY) continue;
+            const int32_t xl = (int32_t)((double)((float)x + d) + 0.5);
+            if (xl >= 0 && xl < W) {
+                const float l = dl[(size_t)y * W + xl];
+                if (l == INFINITY) continue;
+                if (fabs(d - l) > thres) *p = INFINITY;
+            } else {
+                *p = INFINITY;
+            }
+        }
+}
+
 /* ---------------------------------------------------------------- speckles */
 
 void sgmo_remove_speckles(float* disp, int W, int H, float diff_insame, unsigned min_area)
@@ -352,6 +412,9 @@ struct sgmo_ctx {
     sgmo_option opt;
     int W, H, D;
     int honor_num_paths;
+    int census_w, census_h;   /* 0 = the reference's 5x5 */
+    int reference_view;       /* 0 = left (reference), 1 = right (extension) */
+    uint64_t *census64_l, *census64_r;
     bool ready;
     uint32_t *census_l, *census_r;
     uint8_t* cost;
@@ -365,6 +428,8 @@ sgmo_ctx* sgmo_create(void) { return (sgmo_ctx*)calloc(1, sizeof(sgmo_ctx)); }
 static void release_buffers(sgmo_ctx* c)
 {
     free(c->census_l); free(c->census_r); free(c->cost); free(c->aggr);
+    free(c->census64_l); free(c->census64_r);
+    c->census64_l = c->census64_r = NULL;
     for (int i = 0; i < 5; ++i) free(c->stage_f[i]);
     c->census_l = c->census_r = NULL; c->cost = NULL; c->aggr = NULL;
     memset(c->stage_f, 0, sizeof c->stage_f);
@@ -378,6 +443,16 @@ void sgmo_destroy(sgmo_ctx* c)
 }
 
 void sgmo_set_honor_num_paths(sgmo_ctx* c, int honor) { c->honor_num_paths = honor; }
+
+/* extensions (see sgmo_census_window / sgmo_lrcheck_right); both take effect at the next sgmo_match */
+bool sgmo_set_census_window(sgmo_ctx* c, int cw, int ch)
+{
+    if (cw < 1 || ch < 1 || !(cw & 1) || !(ch & 1) || cw * ch > 64) return false;
+    if (cw == 5 && ch == 5) cw = ch = 0;
+    c->census_w = cw; c->census_h = ch;
+    return true;
+}
+void sgmo_set_reference_view(sgmo_ctx* c, int right) { c->reference_view = right ? 1 : 0; }
 
 bool sgmo_initialize(sgmo_ctx* c, uint16_t width, uint16_t height, const sgmo_option* opt)
 {
@@ -414,9 +489,20 @@ bool sgmo_match(sgmo_ctx* c, const uint8_t* left, const uint8_t* right, float* o
     const sgmo_option* o = &c->opt;
     const size_t px = (size_t)W * H;
 
-    sgmo_census5x5(left, W, H, c->census_l);
-    sgmo_census5x5(right, W, H, c->census_r);
-    sgmo_cost(c->census_l, c->census_r, W, H, o->min_disparity, o->max_disparity, c->cost);
+    if (c->census_w == 0) {
+        sgmo_census5x5(left, W, H, c->census_l);
+        sgmo_census5x5(right, W, H, c->census_r);
+        sgmo_cost(c->census_l, c->census_r, W, H, o->min_disparity, o->max_disparity, c->cost);
+    } else {
+        if (!c->census64_l) {
+            c->census64_l = (uint64_t*)malloc(px * sizeof(uint64_t));
+            c->census64_r = (uint64_t*)malloc(px * sizeof(uint64_t));
+            if (!c->census64_l || !c->census64_r) return false;
+        }
+        sgmo_census_window(left, W, H, c->census_w, c->census_h, c->census64_l);
+        sgmo_census_window(right, W, H, c->census_w, c->census_h, c->census64_r);
+        sgmo_cost64(c->census64_l, c->census64_r, W, H, o->min_disparity, o->max_disparity, c->cost);
+    }
 
     g_wraps = g_dropped = 0;
     const int n_dirs = (c->honor_num_paths && o->num_paths == 4) ? 4 : 8;     /* Q1 */
@@ -428,10 +514,15 @@ bool sgmo_match(sgmo_ctx* c, const uint8_t* left, const uint8_t* right, float* o
     sgmo_wta(c->aggr, W, H, o->min_disparity, o->max_disparity, o->is_check_unique, o->uniqueness_ratio, 0, cur);
     memcpy(c->stage_f[2], cur, px * sizeof(float));
     cur = c->stage_f[2];
-    if (o->is_check_lr) {
+    if (o->is_check_lr || c->reference_view) {
         sgmo_wta(c->aggr, W, H, o->min_disparity, o->max_disparity, o->is_check_unique, o->uniqueness_ratio, 1,
                  c->stage_f[1]);
-        sgmo_lrcheck(cur, c->stage_f[1], W, H, o->lrcheck_thres);
+        if (c->reference_view) {                              /* extension: the right view's map, checked against the left */
+            memcpy(cur, c->stage_f[1], px * sizeof(float));
+            if (o->is_check_lr) sgmo_lrcheck_right(cur, c->stage_f[0], W, H, o->lrcheck_thres);
+        } else {
+            sgmo_lrcheck(cur, c->stage_f[1], W, H, o->lrcheck_thres);
+        }
     }
     memcpy(c->stage_f[3], cur, px * sizeof(float));
     cur = c->stage_f[3];
@@ -448,8 +539,8 @@ const void* sgmo_stage(const sgmo_ctx* c, int which, size_t* bytes)
     size_t n = 0;
     const void* p = NULL;
     switch (which) {
-    case 0: p = c->census_l; n = px * 4; break;
-    case 1: p = c->census_r; n = px * 4; break;
+    case 0: p = c->census_w ? (const void*)c->census64_l : (const void*)c->census_l; n = px * (c->census_w ? 8 : 4); break;
+    case 1: p = c->census_w ? (const void*)c->census64_r : (const void*)c->census_r; n = px * (c->census_w ? 8 : 4); break;
     case 2: p = c->cost; n = px * c->D; break;
     case 3: p = c->aggr; n = px * c->D * 2; break;
     default:

@@ -49,6 +49,11 @@ typedef struct {
 /* SemiGlobalMatching.c:134-159.  Border (2 px) is written as 0 (Q3). */
 void sgmo_census5x5(const uint8_t* img, int W, int H, uint32_t* census);
 
+/* Extension, pinned by this restatement only: the census transform for any odd window cw x ch of at most 64 pixels
+ * (u64 words; equals sgmo_census5x5 for 5x5) and its Hamming cost. */
+void sgmo_census_window(const uint8_t* img, int W, int H, int cw, int ch, uint64_t* census);
+void sgmo_cost64(const uint64_t* cl, const uint64_t* cr, int W, int H, int dmin, int dmax, uint8_t* cost);
+
 /* SemiGlobalMatching.c:161-196.  cost[(y*W+x)*D + (d-dmin)]. */
 void sgmo_cost(const uint32_t* cl, const uint32_t* cr, int W, int H,
                int dmin, int dmax, uint8_t* cost);
@@ -81,6 +86,9 @@ void sgmo_wta(const uint16_t* S, int W, int H, int dmin, int dmax,
 /* SemiGlobalMatching.c:445-470 (in place on disp_left). */
 void sgmo_lrcheck(float* disp_left, const float* disp_right, int W, int H, float thres);
 
+/* Extension: the mirror image of the LR check with the right view as the reference view (in place on disp_right). */
+void sgmo_lrcheck_right(float* disp_right, const float* disp_left, int W, int H, float thres);
+
 /* SemiGlobalMatching.c:585-642 (diff_insame = 1 in the reference call, .c:115). */
 void sgmo_remove_speckles(float* disp, int W, int H, float diff_insame, unsigned min_area);
 
@@ -99,6 +107,11 @@ typedef struct sgmo_ctx sgmo_ctx;
 sgmo_ctx* sgmo_create(void);
 void      sgmo_destroy(sgmo_ctx* c);
 void      sgmo_set_honor_num_paths(sgmo_ctx* c, int honor);
+/* extensions beyond the reference, each defined by this restatement alone:
+ * census window cw x ch (odd, <= 64 pixels; 5x5 = reference; stages 0/1 are then uint64 words) and the view the
+ * result is referenced to (0 left = reference; 1 right: stage 6.. hold the right view's map, LR-checked against the left) */
+bool      sgmo_set_census_window(sgmo_ctx* c, int cw, int ch);
+void      sgmo_set_reference_view(sgmo_ctx* c, int right);
 bool      sgmo_initialize(sgmo_ctx* c, uint16_t width, uint16_t height, const sgmo_option* opt);
 bool      sgmo_reset(sgmo_ctx* c, uint16_t width, uint16_t height, const sgmo_option* opt);
 bool      sgmo_match(sgmo_ctx* c, const uint8_t* left, const uint8_t* right, float* disp_left);

@@ -2,18 +2,18 @@
 
 // kernels for negative P1 live in sgm_aggregate_generic.hip (their own translation unit: parallel build)
 bool sgmd_aggregate_launch_generic(int lpp, int dpl, const AggArgs* a, int blocks, int pad, hipStream_t st);
+bool sgmd_aggregate_launch_volume(int dpl, const AggArgs* a, int blocks, int pad, hipStream_t st);
 
-extern "C" {
-
-int sgmd_aggregate(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* paths, const void* img_left,
-                   const void* census_l, const void* census_r, const void* lut, void* planes, size_t plane_bytes,
-                   void* extras)
+static int aggregate_any(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* paths, const void* img_left,
+                         const void* census_l, const void* census_r, const void* cost, const void* lut, void* planes,
+                         size_t plane_bytes, void* extras)
 {
     HIP_TRY(hipSetDevice(ord));
     AggArgs a;
     a.img = (const uint8_t*)img_left;
     a.census_l = (const uint32_t*)census_l;
     a.census_r = (const uint32_t*)census_r;
+    a.cost = (const uint8_t*)cost;
     a.dmin = g->dmin;
     a.lut = (const uint16_t*)lut;
     a.planes = (uint8_t*)planes;
@@ -26,31 +26,54 @@ int sgmd_aggregate(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* 
     a.p1 = paths->p1;
     a.ndirs = paths->ndirs;
     a.ghost_zero = paths->ghost_zero;
+    // SGM_DIR_MASK (diagnostics only: wrong results): run a subset of the directions, to time them apart
+    static const int debug_mask = getenv("SGM_DIR_MASK") ? (int)strtol(getenv("SGM_DIR_MASK"), nullptr, 0) : 0xFF;
     int blocks = 0;
     for (int d = 0; d < 8; ++d) {
         a.dx[d] = paths->dx[d]; a.dy[d] = paths->dy[d]; a.anom_line[d] = paths->anom_line[d];
         a.block_begin[d] = blocks;
-        if (d < paths->ndirs && ((paths->dir_mask >> d) & 1)) {
+        if (d < paths->ndirs && ((paths->dir_mask & debug_mask) >> d) & 1) {
             const int nlines = (paths->dy[d] == 0) ? g->row_end - g->row_begin : g->W;
             const int lines_per_wave = 64 / ((paths->dy[d] == 0 && g->HL) ? g->HL : g->LPP);
             blocks += (nlines + lines_per_wave - 1) / lines_per_wave;
         }
     }
     a.block_begin[8] = blocks;
+    if (debug_mask != 0xFF) a.run_anom = 0;
     if (a.run_anom) blocks += 4;                       // one extra wave per diagonal direction: its anomalous line
     if (blocks == 0) return 0;
     blocks *= g->B;                                    // every frame of the batch in the same launch
     const bool pad = (g->D != g->Dp);
     hipStream_t st = (hipStream_t)stream;
     bool launched;
-    if (a.p1 >= 0) launched = launch_aggregate_key<true>(g->LPP, g->DPL, a, blocks, pad, g->HL, st);
-    else           launched = sgmd_aggregate_launch_generic(g->LPP, g->DPL, &a, blocks, pad ? 1 : 0, st);
+    if (cost)           launched = sgmd_aggregate_launch_volume(g->DPL, &a, blocks, pad ? 1 : 0, st);
+    else if (a.p1 >= 0) launched = launch_aggregate_key<true>(g->LPP, g->DPL, a, blocks, pad, g->HL, st);
+    else                launched = sgmd_aggregate_launch_generic(g->LPP, g->DPL, &a, blocks, pad ? 1 : 0, st);
     if (!launched) {
         fprintf(stderr, "sgm_mi355x: unsupported lanes-per-pixel/DPL combination %d/%d\n", g->LPP, g->DPL);
         return -1;
     }
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+extern "C" {
+
+int sgmd_aggregate(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* paths, const void* img_left,
+                   const void* census_l, const void* census_r, const void* lut, void* planes, size_t plane_bytes,
+                   void* extras)
+{
+    return aggregate_any(ord, stream, g, paths, img_left, census_l, census_r, nullptr, lut, planes, plane_bytes, extras);
+}
+
+int sgmd_aggregate_volume(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* paths, const void* img_left,
+                          const void* cost, const void* lut, void* planes, size_t plane_bytes, void* extras)
+{
+    if (g->LPP != 16 || g->HL != 0) {
+        fprintf(stderr, "sgm_mi355x: the volume-fed aggregation needs 16 lanes per pixel on every line\n");
+        return -1;
+    }
+    return aggregate_any(ord, stream, g, paths, img_left, nullptr, nullptr, cost, lut, planes, plane_bytes, extras);
 }
 
 }  // extern "C"

@@ -18,6 +18,7 @@ struct AggArgs {
     const uint8_t* img;
     const uint32_t* census_l;
     const uint32_t* census_r;   // the allocation has >= dmin + Dp dwords of slack in front (reads left of column 0)
+    const uint8_t* cost;        // VOL kernels only: the materialised cost volume u8 [B][H][W][Dp] (census pointers unused)
     int dmin;
     const uint16_t* lut;        // (uint16) max(P1, P2 / (|dg| + 1)), 256 entries (ref :335)
     uint8_t* planes;
@@ -41,6 +42,7 @@ struct AggFrame {
     const uint8_t* img;
     const uint32_t* census_l;
     const uint32_t* census_r;
+    const uint8_t* cost;
     uint8_t* planes;
     uint8_t* extras;
 };
@@ -89,6 +91,25 @@ static __device__ __forceinline__ void census_costs(unsigned cl, const CensusVec
             C[j] = as_p((as_u(C[j]) & ~m) | (0x007F007Fu & m));           // UINT8_MAX/2 (ref :170-171)
         }
     }
+}
+
+// VOL kernels: the lane's DPL cost bytes (loaded from the volume into cv.r[0..]) -> packed u16 pairs
+template <int DPL>
+static __device__ __forceinline__ void volume_costs(const CensusVec<DPL>& cv, us2 (&C)[DPL / 2])
+{
+#pragma unroll
+    for (int j = 0; j < DPL / 2; ++j) {
+        const unsigned w = cv.r[j >> 1];
+        C[j] = as_p(__builtin_amdgcn_perm(w, w, (j & 1) ? 0x0c030c02u : 0x0c010c00u));
+    }
+}
+template <int DPL>
+static __device__ __forceinline__ void load_volume(const uint8_t* p, CensusVec<DPL>& cv)
+{
+    CellVec<DPL> c;
+    load_cells<DPL>(p, c);
+#pragma unroll
+    for (int i = 0; i < (DPL + 3) / 4; ++i) cv.r[i] = c.w[i];
 }
 
 // One aggregation step for the 4 lines of a wave: returns the new packed L_r in Ln and the new
@@ -166,8 +187,9 @@ static __device__ __forceinline__ unsigned agg_step_nn(unsigned cl, const Census
                                                        CellVec<DPL>& packed_out)
 {
     constexpr int NP = DPL / 2;
-    const us2 p2v = as_p((pen16 & 0xFFFFu) * 0x00010001u);
-    const us2 mp = as_p(min_prev | (min_prev << 16));
+    const us2 p2v = as_p(pen16);                                    // both halves hold the penalty (32-bit table)
+    const unsigned mp = min_prev | (min_prev << 16);
+    const unsigned p1u = as_u(p1v);
     unsigned from_left, from_right;
     if (LPP >= 32) {
         from_left = dpp_mov<0x138 /* wave_shr:1 */>(0x00FF00FFu, as_u(Lp[NP - 1]));
@@ -185,11 +207,13 @@ static __device__ __forceinline__ unsigned agg_step_nn(unsigned cl, const Census
     for (int j = 0; j < NP; ++j) {
         const unsigned below = (j == 0) ? from_left : as_u(Lp[j - 1]);
         const unsigned above = (j == NP - 1) ? from_right : as_u(Lp[j + 1]);
-        const us2 dm1 = as_p(__builtin_amdgcn_alignbit(as_u(Lp[j]), below, 16));
-        const us2 dp1 = as_p(__builtin_amdgcn_alignbit(above, as_u(Lp[j]), 16));
-        us2 m = pk_min(dm1 + p1v, dp1 + p1v);
+        // plain 32-bit add / subtract instead of v_pk_add_u16 / v_pk_sub_u16 (full rate against half rate, tools/ubench):
+        // no carry or borrow crosses the halves -- Lp <= 255, 0 <= P1 <= 32767, and every candidate is >= min_prev
+        const us2 dm1 = as_p(__builtin_amdgcn_alignbit(as_u(Lp[j]), below, 16) + p1u);
+        const us2 dp1 = as_p(__builtin_amdgcn_alignbit(above, as_u(Lp[j]), 16) + p1u);
+        us2 m = pk_min(dm1, dp1);
         m = pk_min(m, Lp[j]);
-        md[j] = as_u(pk_min(m - mp, p2v));
+        md[j] = as_u(pk_min(as_p(as_u(m) - mp), p2v));
         const unsigned lo = bcnt_acc(cl ^ cv.r[DPL - 1 - 2 * j], md[j]);              // C(2j) + md, high half = md's
         w[j] = shl16_add((unsigned)__popc(cl ^ cv.r[DPL - 2 - 2 * j]), lo);           // + C(2j+1) << 16
     }
@@ -222,9 +246,14 @@ enum { AGG_H = 0, AGG_V = 1, AGG_D = 2 };
 // (the host guarantees W*H*Dp < 2^32); the walk is the reference's (ref :281-323, 359-367) with the
 // row test dropped (a regular line is never in the last row before its final step) and the two
 // edge tests turned into selects.
-template <int DPL, bool PAD, int LPP, int KIND, bool NN>
+// WIDE (diagonal lines only): W > H.  A regular line of such an image wraps at most once, exactly where its true column
+// leaves the image, so the walk is the closed form of SURVEY.md Q5 -- pixel (k, (i + dx k) mod W) -- and costs 7
+// instructions per step instead of the ~17 of the reference's two-tracker state machine (which W <= H still needs:
+// there the off-by-one tracker makes lines wrap early).
+// VOL: the matching cost comes from a materialised volume (wide census windows) instead of the census images.
+template <int DPL, bool PAD, int LPP, int KIND, bool NN, bool WIDE = false, bool VOL = false>
 static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFrame& fr, const unsigned short* lut_s,
-                                                   int dir, int grp)
+                                                   const unsigned* lut32_s, int dir, int grp)
 {
     constexpr int NP = DPL / 2;
     constexpr int PF = (LPP >= 32) ? 4 : 2;                              // prefetch depth (steps): 2 keeps the 8-lines-per-wave kernel at 8 waves/SIMD; the latency-critical 32-lane lines look further ahead
@@ -290,6 +319,10 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
     }
     off = p * (unsigned)Dp + lane_off;
     const int col_step = (dx == dy) ? s : -s;                              // ref :360-367
+    // WIDE: column the line wraps from / to, and the pixel / byte steps of an ordinary and of a wrapping move
+    const unsigned wrap_at = (col_step > 0) ? (unsigned)(W - 1) : 0u, wrap_to = (col_step > 0) ? 0u : (unsigned)(W - 1);
+    const unsigned pstep_n = (unsigned)(dstep_p + col_step), pstep_w = (unsigned)(dstep_p - col_step * (W - 1));
+    const unsigned ostep_n = pstep_n * (unsigned)Dp, ostep_w = pstep_w * (unsigned)Dp;
     // census-right words of this lane's disparities start (ascending addresses) at pixel p - back
     const int back = a.dmin + (int)lane_off + DPL - 1;
     const int lim_bias = a.dmin + (int)lane_off;                           // disparity i of the lane is in the image iff i <= x - lim_bias
@@ -302,6 +335,12 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
         } else if (KIND == AGG_V) {
             p += (unsigned)dstep_p;
             off += (unsigned)dstep_off;
+        } else if (WIDE) {
+            const bool wrap = (pcol == wrap_at);
+            pcol = wrap ? wrap_to : pcol + (unsigned)col_step;
+            p += wrap ? pstep_w : pstep_n;
+            off += wrap ? ostep_w : ostep_n;
+            x = (int)pcol;
         } else {
             const bool wr = (col == (unsigned)(W - 1));                    // ref :297 (tracker, not true column)
             const bool wl = !wr && (col == 0);                             // ref :304
@@ -315,8 +354,13 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
         }
     };
     auto fetch = [&](CensusVec<DPL>& cv, unsigned& cl, int& g) {
-        load_census<DPL>(fr.census_r + ((long long)p - back), cv);
-        cl = fr.census_l[p];
+        if constexpr (VOL) {
+            load_volume<DPL>(fr.cost + off, cv);
+            cl = 0;
+        } else {
+            load_census<DPL>(fr.census_r + ((long long)p - back), cv);
+            cl = fr.census_l[p];
+        }
         g = fr.img[p];
     };
 
@@ -348,7 +392,8 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
         unsigned cl;
         fetch(cv, cl, g_prev);
         const int lim = x - lim_bias;
-        census_costs<DPL>(cl, cv, lim, true, Lp);
+        if constexpr (VOL) volume_costs<DPL>(cv, Lp);
+        else census_costs<DPL>(cl, cv, lim, true, Lp);
         if (PAD) {
 #pragma unroll
             for (int j = 0; j < NP; ++j) Lp[j] = as_p(as_u(Lp[j]) | as_u(padmask[j]));
@@ -388,10 +433,10 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
         const int g = gb[u];
         const int lim = limb[u];
         const unsigned o = ob[u];
-        const int dg = g > g_prev ? g - g_prev : g_prev - g;
+        const unsigned dg = __builtin_amdgcn_sad_u8((unsigned)g, (unsigned)g_prev, 0u);   // |g - g_prev| (grey values: one byte)
         CellVec<DPL> packed;
         if constexpr (NN) {
-            min_prev = agg_step_nn<DPL, PAD, LPP>(clb[u], cb[u], lim, __any(lim < DPL - 1) != 0, Lp, min_prev, lut_s[dg], p1v,
+            min_prev = agg_step_nn<DPL, PAD, LPP>(clb[u], cb[u], lim, __any(lim < DPL - 1) != 0, Lp, min_prev, lut32_s[dg], p1v,
                                                   padmask, first_lane, last_lane, packed);
             if (refill) {                                                      // the slot's census words are consumed now
                 advance();
@@ -401,7 +446,8 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
             }
         } else {
             us2 C[NP];
-            census_costs<DPL>(clb[u], cb[u], lim, __any(lim < DPL - 1) != 0, C);   // consume the slot, then refill it
+            if constexpr (VOL) volume_costs<DPL>(cb[u], C);
+            else census_costs<DPL>(clb[u], cb[u], lim, __any(lim < DPL - 1) != 0, C);   // consume the slot, then refill it
             if (refill) {
                 advance();
                 ob[u] = off;
@@ -432,7 +478,7 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
 // also visited by regular lines), and it zeroes the cells no line visits (W >= H: the track it
 // should have taken).  One wave per diagonal direction; all four DPP rows compute the same line,
 // row 0 stores.
-template <int DPL, bool PAD, int LPP>
+template <int DPL, bool PAD, int LPP, bool VOL = false>
 static __device__ __forceinline__ void agg_anomalous(const AggArgs& a, const AggFrame& fr, const unsigned short* lut_s,
                                                      int dir)
 {
@@ -487,9 +533,14 @@ static __device__ __forceinline__ void agg_anomalous(const AggArgs& a, const Agg
     const int lim_bias = a.dmin + (int)lane_off;
     {
         CensusVec<DPL> cv;
-        load_census<DPL>(fr.census_r + (p - back), cv);
         g_prev = fr.img[p];
-        census_costs<DPL>(fr.census_l[p], cv, (int)(p % W) - lim_bias, true, Lp);
+        if constexpr (VOL) {
+            load_volume<DPL>(fr.cost + (size_t)p * Dp + lane_off, cv);
+            volume_costs<DPL>(cv, Lp);
+        } else {
+            load_census<DPL>(fr.census_r + (p - back), cv);
+            census_costs<DPL>(fr.census_l[p], cv, (int)(p % W) - lim_bias, true, Lp);
+        }
         if (PAD) {
 #pragma unroll
             for (int j = 0; j < NP; ++j) Lp[j] = as_p(as_u(Lp[j]) | as_u(padmask[j]));
@@ -521,9 +572,14 @@ static __device__ __forceinline__ void agg_anomalous(const AggArgs& a, const Agg
             CellVec<DPL> packed;
             CensusVec<DPL> cv;
             us2 C[NP];
-            load_census<DPL>(fr.census_r + (p - back), cv);
             const int g = fr.img[p];
-            census_costs<DPL>(fr.census_l[p], cv, (int)(p % W) - lim_bias, true, C);
+            if constexpr (VOL) {
+                load_volume<DPL>(fr.cost + (size_t)p * Dp + lane_off, cv);
+                volume_costs<DPL>(cv, C);
+            } else {
+                load_census<DPL>(fr.census_r + (p - back), cv);
+                census_costs<DPL>(fr.census_l[p], cv, (int)(p % W) - lim_bias, true, C);
+            }
             const int dg = g > g_prev ? g - g_prev : g_prev - g;
             min_prev = agg_step<DPL, PAD, LPP>(C, Lp, min_prev, lut_s[dg], p1v, padmask, first_lane, last_lane, packed);
             g_prev = g;
@@ -535,13 +591,18 @@ static __device__ __forceinline__ void agg_anomalous(const AggArgs& a, const Agg
 
 // NN: the step for non-negative P1 (agg_step_nn); the generic step only serves negative P1, for which the host
 // keeps to 16 lanes per pixel everywhere (sgm_host.c), so only those combinations are instantiated without NN
-template <int DPL, bool PAD, int LPP, int HL, bool NN>
+template <int DPL, bool PAD, int LPP, int HL, bool NN, bool VOL = false>
 __global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
 {
     __shared__ unsigned short lut_s[256];
+    __shared__ unsigned lut32_s[256];                        // the same penalties in both halves of a dword (packed u16 operand)
     const int lane = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) lut_s[lane * 4 + i] = a.lut[lane * 4 + i];
+    for (int i = 0; i < 4; ++i) {
+        const unsigned pen = a.lut[lane * 4 + i];
+        lut_s[lane * 4 + i] = (unsigned short)pen;
+        lut32_s[lane * 4 + i] = pen * 0x00010001u;
+    }
     __syncthreads();
 
     // Batch: consecutive blocks are the same line group of consecutive frames, so every frame's long
@@ -553,10 +614,11 @@ __global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
     fr.img = a.img + (size_t)frame * a.W * a.H;
     fr.census_l = a.census_l + (size_t)frame * a.W * a.H;
     fr.census_r = a.census_r + (size_t)frame * a.W * a.H;
+    fr.cost = VOL ? a.cost + (size_t)frame * a.W * a.H * a.Dp : nullptr;
     fr.planes = a.planes + (size_t)frame * 8 * a.plane_bytes;
     fr.extras = a.extras + (size_t)frame * 4 * a.H * a.Dp;
     if (b >= a.block_begin[8]) {
-        agg_anomalous<DPL, PAD, LPP>(a, fr, lut_s, 4 + (b - a.block_begin[8]));
+        agg_anomalous<DPL, PAD, LPP, VOL>(a, fr, lut_s, 4 + (b - a.block_begin[8]));
         return;
     }
     int dir = 0;
@@ -569,11 +631,12 @@ __global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
     // they get 32 lanes per pixel -- fewer disparities per lane, the shortest step -- while the vertical and
     // diagonal lines keep the lane count that costs the fewest instructions per cell
     if (a.dy[dir] == 0) {
-        if constexpr (HL != 0) agg_regular<DPL * LPP / HL, PAD, HL, AGG_H, NN>(a, fr, lut_s, dir, grp);
-        else               agg_regular<DPL, PAD, LPP, AGG_H, NN>(a, fr, lut_s, dir, grp);
+        if constexpr (HL != 0) agg_regular<DPL * LPP / HL, PAD, HL, AGG_H, NN, false, VOL>(a, fr, lut_s, lut32_s, dir, grp);
+        else               agg_regular<DPL, PAD, LPP, AGG_H, NN, false, VOL>(a, fr, lut_s, lut32_s, dir, grp);
     }
-    else if (a.dx[dir] == 0) agg_regular<DPL, PAD, LPP, AGG_V, NN>(a, fr, lut_s, dir, grp);
-    else                     agg_regular<DPL, PAD, LPP, AGG_D, NN>(a, fr, lut_s, dir, grp);
+    else if (a.dx[dir] == 0) agg_regular<DPL, PAD, LPP, AGG_V, NN, false, VOL>(a, fr, lut_s, lut32_s, dir, grp);
+    else if (a.W > a.H)      agg_regular<DPL, PAD, LPP, AGG_D, NN, true, VOL>(a, fr, lut_s, lut32_s, dir, grp);
+    else                     agg_regular<DPL, PAD, LPP, AGG_D, NN, false, VOL>(a, fr, lut_s, lut32_s, dir, grp);
 }
 
 template <int DPL, int LPP, int HL, bool NN>
@@ -623,3 +686,4 @@ static bool launch_aggregate_key(int lpp, int dpl, const AggArgs& a, int blocks,
     }
     return false;
 }
+

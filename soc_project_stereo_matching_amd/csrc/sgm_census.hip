@@ -63,7 +63,88 @@ __global__ __launch_bounds__(256) void sgm_cost_k(const uint32_t* __restrict__ c
 }
 
 
+// ============================================================================================
+// Extension (the reference only has 5x5): census over any odd window cw x ch of at most 64 pixels,
+// u64 words, same bit order (raster, first comparison in the highest bit, centre included) and zero border; and the
+// Hamming cost of those words as a materialised u8 volume for the volume-fed aggregation kernels.
+// ============================================================================================
+
+__global__ __launch_bounds__(256) void sgm_census_window_k(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
+                                                           unsigned long long* __restrict__ cl, unsigned long long* __restrict__ cr,
+                                                           int W, int H, int cw, int ch)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const size_t frame_px = (size_t)(blockIdx.z >> 1) * W * H;
+    const uint8_t* img = ((blockIdx.z & 1) ? right : left) + frame_px;
+    unsigned long long* out = ((blockIdx.z & 1) ? cr : cl) + frame_px;
+    const int rx = cw / 2, ry = ch / 2;
+    unsigned long long bits = 0;
+    if (W > cw && H > ch && x >= rx && x < W - rx && y >= ry && y < H - ry) {
+        const unsigned centre = img[(size_t)y * W + x];
+        for (int r = -ry; r <= ry; ++r)
+            for (int c = -rx; c <= rx; ++c) bits = (bits << 1) | (unsigned long long)(img[(size_t)(y + r) * W + (x + c)] < centre);
+    }
+    out[(size_t)y * W + x] = bits;
+}
+
+__global__ __launch_bounds__(256) void sgm_cost64_k(const unsigned long long* __restrict__ cl, const unsigned long long* __restrict__ cr,
+                                                    uint8_t* __restrict__ cost, int W, int H, int D, int Dp, int dmin)
+{
+    const int chunks = Dp >> 4;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)W * H * chunks;
+    if (t >= total) return;
+    cl += (size_t)blockIdx.y * W * H;
+    cr += (size_t)blockIdx.y * W * H;
+    cost += (size_t)blockIdx.y * W * H * Dp;
+    const int chunk = (int)(t % chunks);
+    const long long pix = t / chunks;
+    const int x = (int)(pix % W);
+    const unsigned long long a = cl[pix];
+    const unsigned long long* rrow = cr + (pix - x);
+    unsigned w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned word = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int di = chunk * 16 + q * 4 + b;
+            const int xr = x - (dmin + di);
+            unsigned c = 127u;                        // off-image: UINT8_MAX/2 (ref :170-171); padding cells too (never read back)
+            if (di < D && xr >= 0 && xr < W) c = (unsigned)__popcll(a ^ rrow[xr]);
+            word |= c << (8 * b);
+        }
+        w[q] = word;
+    }
+    *reinterpret_cast<uint4*>(cost + pix * Dp + chunk * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+
 extern "C" {
+
+int sgmd_census_window(int ord, void* stream, const sgmd_geom* g, int cw, int ch, const void* left, const void* right, void* cl64,
+                       void* cr64)
+{
+    HIP_TRY(hipSetDevice(ord));
+    dim3 grid((g->W + 63) / 64, (g->H + 3) / 4, 2 * g->B);
+    hipLaunchKernelGGL(sgm_census_window_k, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)left, (const uint8_t*)right,
+                       (unsigned long long*)cl64, (unsigned long long*)cr64, g->W, g->H, cw, ch);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sgmd_cost64(int ord, void* stream, const sgmd_geom* g, const void* cl64, const void* cr64, void* cost)
+{
+    HIP_TRY(hipSetDevice(ord));
+    const long long total = (long long)g->W * g->H * (g->Dp / 16);
+    dim3 grid((unsigned)((total + 255) / 256), g->B);
+    hipLaunchKernelGGL(sgm_cost64_k, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned long long*)cl64,
+                       (const unsigned long long*)cr64, (uint8_t*)cost, g->W, g->H, g->D, g->Dp, g->dmin);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 
 size_t sgmd_census_slack(const sgmd_geom* g)
 {

@@ -77,6 +77,12 @@ int sgmd_census(int ord, void* stream, const sgmd_geom* g, const void* left, con
 /* Hamming matching cost volume, u8 [H][W][Dp].  SemiGlobalMatching.c:161-196 */
 int sgmd_cost(int ord, void* stream, const sgmd_geom* g, const void* census_l, const void* census_r, void* cost);
 
+/* Extension: census over an odd cw x ch window of at most 64 pixels into u64 words, and the Hamming cost
+ * volume of those words (u8 [H][W][Dp], as sgmd_cost); sgmd_aggregate then takes the volume instead of the census images */
+int sgmd_census_window(int ord, void* stream, const sgmd_geom* g, int cw, int ch, const void* left, const void* right,
+                       void* census64_l, void* census64_r);
+int sgmd_cost64(int ord, void* stream, const sgmd_geom* g, const void* census64_l, const void* census64_r, void* cost);
+
 /* All directions of the path aggregation in ONE launch.  SemiGlobalMatching.c:198-372.
  * The matching cost (SemiGlobalMatching.c:161-196) is recomputed from the census images inside the
  * kernel; census_r must be preceded by at least sgmd_census_slack(g) readable bytes (disparities that
@@ -87,6 +93,10 @@ size_t sgmd_census_slack(const sgmd_geom* g);
 int sgmd_aggregate(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* paths, const void* img_left,
                    const void* census_l, const void* census_r, const void* lut, void* planes, size_t plane_bytes,
                    void* extras);
+/* the same aggregation fed from a materialised cost volume (sgmd_cost / sgmd_cost64) instead of recomputing the cost:
+ * what the wide census windows use (generic step, 16 lanes per pixel) */
+int sgmd_aggregate_volume(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* paths, const void* img_left,
+                          const void* cost, const void* lut, void* planes, size_t plane_bytes, void* extras);
 
 /* S = (accumulate ? S : 0) + sum of planes + anomalous-line visits (u16 [H][W][Dp]) and, fused, the LEFT-view
  * winner-take-all with uniqueness and sub-pixel (SemiGlobalMatching.c:374-443, inverse == 0) -> disp_l */
@@ -108,6 +118,11 @@ int sgmd_wta_right(int ord, void* stream, const sgmd_geom* g, const void* S, int
 
 /* SemiGlobalMatching.c:445-470 */
 int sgmd_lrcheck(int ord, void* stream, const sgmd_geom* g, void* disp_l, const void* disp_r, float thres);
+
+/* Extension: the right view as the reference view.  out = disp_r where the mirrored check against disp_l passes (all of
+ * disp_r if !do_check), +INF elsewhere; out must not alias either input */
+int sgmd_lrcheck_right(int ord, void* stream, const sgmd_geom* g, const void* disp_r, const void* disp_l, float thres,
+                       int do_check, void* out);
 
 /* connected components (|delta| <= diff, 8-neighbourhood) smaller than min_area -> +INF.
  * labels/sizes/totals: int32 [H][W] scratch each.  SemiGlobalMatching.c:585-642 */

@@ -36,6 +36,8 @@ struct sgm_instance {
     int timing;
     int keep_stages;
     int honor_num_paths;
+    int census_w, census_h;      /* census window (sgm_set_census_window); 0 = the reference's 5x5 */
+    int reference_view;          /* 0 = left (reference), 1 = right (sgm_set_reference_view) */
     int batch;                   /* frames per match call (>= 1); takes effect at the next initialize */
     int read_frame;              /* which frame of the batch sgm_read_stage returns */
     int tile_begin, tile_end;    /* row tile this instance computes (sgm_set_rows); tile_end == 0: the whole frame */
@@ -70,6 +72,8 @@ struct sgm_instance {
                                     position; d_cost and d_S exist only once somebody needs them (stage read-back, Q14, D > 256) */
     void *d_disp, *d_disp_r, *d_labels, *d_sizes, *d_lut, *d_row_extras, *d_row_count;
     void *d_snap_wta, *d_snap_lr, *d_snap_speckle, *d_totals, *d_median_scratch;
+    void *d_census64_l, *d_census64_r;   /* u64 census words of the wide windows (allocated on first use) */
+    size_t cap_census64;
     size_t plane_bytes;
     /* pinned staging for the host-pointer entry point */
     void *h_left, *h_right, *h_disp;
@@ -178,7 +182,7 @@ static void free_device_buffers(sgm_instance* s)
     void** all[] = {&s->d_left, &s->d_right, &s->d_census_l, &s->d_census_r_alloc, &s->d_cost, &s->d_planes_alloc, &s->d_extras,
                     &s->d_S, &s->d_disp, &s->d_disp_r, &s->d_labels, &s->d_sizes, &s->d_lut, &s->d_row_extras,
                     &s->d_row_count, &s->d_snap_wta, &s->d_snap_lr, &s->d_snap_speckle, &s->d_totals,
-                    &s->d_median_scratch};
+                    &s->d_median_scratch, &s->d_census64_l, &s->d_census64_r};
     for (size_t i = 0; i < sizeof all / sizeof all[0]; ++i) {
         sgmd_free(s->device, *all[i]);
         *all[i] = NULL;
@@ -187,7 +191,7 @@ static void free_device_buffers(sgm_instance* s)
     sgmd_free_pinned(s->device, s->h_right);
     sgmd_free_pinned(s->device, s->h_disp);
     s->h_left = s->h_right = s->h_disp = NULL;
-    s->cap_px = s->cap_planes = s->cap_S = s->cap_cost = s->cap_extras = s->cap_median = 0;
+    s->cap_px = s->cap_planes = s->cap_S = s->cap_cost = s->cap_extras = s->cap_median = s->cap_census64 = 0;
     s->cap_H = s->cap_row_cap = 0;
     s->tab_W = s->tab_H = 0;
 }
@@ -204,6 +208,17 @@ void sgm_destroy(sgm_instance* s)
 }
 
 void sgm_set_honor_num_paths(sgm_instance* s, int honor) { if (s) s->honor_num_paths = honor; }
+
+bool sgm_set_census_window(sgm_instance* s, int width, int height)
+{
+    if (!s || width < 1 || height < 1 || !(width & 1) || !(height & 1) || width * height > 64) return false;
+    if (width == 5 && height == 5) width = height = 0;           /* the reference's window: the fused fast path */
+    if (width != s->census_w || height != s->census_h) s->initialized = false;   /* takes effect at the next initialize */
+    s->census_w = width; s->census_h = height;
+    return true;
+}
+
+void sgm_set_reference_view(sgm_instance* s, int right) { if (s) s->reference_view = right ? 1 : 0; }
 void sgm_keep_stages(sgm_instance* s, int enable) { if (s) s->keep_stages = enable; }
 
 bool sgm_set_batch(sgm_instance* s, int frames)
@@ -422,7 +437,8 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
         const int want = (e && *e) ? atoi(e) : (s->batch >= 2 ? 8 : 16);
         /* negative P1 (defined by the reference's C arithmetic, covered by the parity tests, used by nobody) runs the
          * generic aggregation step, which only exists for 16 lanes per pixel */
-        if (want == 8 && option->p1 >= 0 && s->g.DPL >= 2 && s->g.DPL <= 8 && s->g.DPL != 6) { s->g.LPP = 8; s->g.DPL *= 2; }
+        /* the wide census windows feed the aggregation from a cost volume: generic step, 16 lanes per pixel */
+        if (want == 8 && option->p1 >= 0 && !s->census_w && s->g.DPL >= 2 && s->g.DPL <= 8 && s->g.DPL != 6) { s->g.LPP = 8; s->g.DPL *= 2; }
     }
     /* one frame per launch: the horizontal lines (W-1 serial steps) are the longest chains of the launch -> spread each
      * pixel of those over 32 lanes (2 lines per wave).  64 lanes (SGM_HL=64, one line per wave) measures the same at
@@ -434,7 +450,7 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
         int want = (e && *e) ? atoi(e) : (s->batch == 1 ? 32 : 0);
         if (want == 64 && !ok64) want = 32;
         if (want == 32 && !ok32) want = 0;
-        if (want == s->g.LPP || option->p1 < 0) want = 0;
+        if (want == s->g.LPP || option->p1 < 0 || s->census_w) want = 0;
         s->g.HL = want;
     }
     s->g.dmin = option->min_disparity;
@@ -543,7 +559,7 @@ static int sum_and_wta(sgm_instance* s, void* d_out, bool with_marks)
     if (s->fused_wta) {
         const int store = s->keep_stages ? 1 : 0;
         rc = sgmd_sum_wta_lr(s->device, s->stream, &s->g, s->paths.ndirs, s->d_planes, s->plane_bytes, s->d_extras,
-                             s->d_row_extras, s->d_row_count, s->row_cap, accumulate, store, o->is_check_lr ? 1 : 0, s->d_S,
+                             s->d_row_extras, s->d_row_count, s->row_cap, accumulate, store, (o->is_check_lr || s->reference_view) ? 1 : 0, s->d_S,
                              uniq, keep, d_out, s->d_disp_r);
         if (rc != 0) return rc;
         s->s_pending = !store;
@@ -557,11 +573,57 @@ static int sum_and_wta(sgm_instance* s, void* d_out, bool with_marks)
         s->s_pending = false;
         s->s_is_zero = false;
         if (with_marks) mark(s, 4);
-        if (o->is_check_lr) rc = sgmd_wta_right(s->device, s->stream, &s->g, s->d_S, uniq, keep, s->d_disp_r);
+        if (o->is_check_lr || s->reference_view) rc = sgmd_wta_right(s->device, s->stream, &s->g, s->d_S, uniq, keep, s->d_disp_r);
         if (rc != 0) return rc;
     }
     s->s_is_zero = false;
     return 0;
+}
+
+/* .c:82-83 (+ .c:89 for the wide census windows, whose cost is materialised): census of both images */
+static int prepare_costs(sgm_instance* s, const void* d_left, const void* d_right)
+{
+    if (!s->census_w) return sgmd_census(s->device, s->stream, &s->g, d_left, d_right, s->d_census_l, s->d_census_r);
+    const size_t need = (size_t)s->g.B * s->g.W * s->g.H * 8;
+    if (need > s->cap_census64 || !s->d_census64_l) {
+        sgmd_stream_sync(s->device, s->stream);
+        sgmd_free(s->device, s->d_census64_l);
+        sgmd_free(s->device, s->d_census64_r);
+        s->d_census64_l = s->d_census64_r = NULL;
+        s->cap_census64 = 0;
+        if (sgmd_alloc(s->device, &s->d_census64_l, need) != 0 || sgmd_alloc(s->device, &s->d_census64_r, need) != 0) return -1;
+        s->cap_census64 = need;
+    }
+    int rc = ensure_cost(s);
+    if (rc == 0) rc = sgmd_census_window(s->device, s->stream, &s->g, s->census_w, s->census_h, d_left, d_right, s->d_census64_l,
+                                         s->d_census64_r);
+    if (rc == 0) rc = sgmd_cost64(s->device, s->stream, &s->g, s->d_census64_l, s->d_census64_r, s->d_cost);
+    return rc;
+}
+
+/* .c:94: the path aggregation, from the census images or (wide windows) from the cost volume */
+static int launch_aggregation(sgm_instance* s, const sgmd_paths* paths, const void* d_left)
+{
+    if (s->census_w)
+        return sgmd_aggregate_volume(s->device, s->stream, &s->g, paths, d_left, s->d_cost, s->d_lut, s->d_planes, s->plane_bytes,
+                                     s->d_extras);
+    return sgmd_aggregate(s->device, s->stream, &s->g, paths, d_left, s->d_census_l, s->d_census_r, s->d_lut, s->d_planes,
+                          s->plane_bytes, s->d_extras);
+}
+
+/* .c:109 LRCheck on the left map -- or, with the right view as the reference view (extension), the mirrored check on the
+ * right map, whose result replaces the left map in d_out */
+static int lr_stage(sgm_instance* s, void* d_out)
+{
+    const SGMOption* o = &s->opt;
+    if (!s->reference_view) return o->is_check_lr ? sgmd_lrcheck(s->device, s->stream, &s->g, d_out, s->d_disp_r, o->lrcheck_thres) : 0;
+    /* the rows this instance computes: all rows of all frames of the batch, or (batch 1) its row tile */
+    const size_t first = (size_t)s->g.row_begin * s->g.W * sizeof(float);
+    const size_t bytes = ((size_t)(s->g.B - 1) * s->g.H + (size_t)(s->g.row_end - s->g.row_begin)) * s->g.W * sizeof(float);
+    int rc = sgmd_lrcheck_right(s->device, s->stream, &s->g, s->d_disp_r, d_out, o->lrcheck_thres, o->is_check_lr ? 1 : 0, s->d_labels);
+    if (rc == 0)                                              /* d_labels: scratch until the speckle pass */
+        rc = sgmd_d2d_async(s->device, s->stream, (char*)d_out + first, (char*)s->d_labels + first, bytes);
+    return rc;
 }
 
 /* The body of SGM_Match (SemiGlobalMatching.c:80-122) on device buffers.  The first launch that is refused ends the
@@ -579,11 +641,11 @@ static bool run_pipeline(sgm_instance* s, const void* d_left, const void* d_righ
 
     if (!s->s_is_zero) LAUNCH(materialize_S(s));             /* Match without Reset: S of the previous frame is needed now */
     mark(s, 0);
-    LAUNCH(sgmd_census(dev, st, g, d_left, d_right, s->d_census_l, s->d_census_r));                /* .c:82-83 */
+    LAUNCH(prepare_costs(s, d_left, d_right));                                                      /* .c:82-83 */
     mark(s, 1);
     /* .c:89: the cost volume is recomputed inside the aggregation kernel; it is only materialised when a
      * test wants to read it back (stage 2) */
-    if (s->keep_stages) {
+    if (s->keep_stages && !s->census_w) {
         LAUNCH(ensure_cost(s));
         LAUNCH(sgmd_cost(dev, st, g, s->d_census_l, s->d_census_r, s->d_cost));
     }
@@ -591,13 +653,12 @@ static bool run_pipeline(sgm_instance* s, const void* d_left, const void* d_righ
     if (s->need_plane_memset && s->paths.ndirs > 4)
         for (int f = 0; f < g->B; ++f)
             LAUNCH(sgmd_memset_async(dev, st, (char*)s->d_planes_alloc + ((size_t)f * 8 + 4) * s->plane_bytes, 0, 4 * s->plane_bytes));
-    LAUNCH(sgmd_aggregate(dev, st, g, &s->paths, d_left, s->d_census_l, s->d_census_r, s->d_lut, s->d_planes, s->plane_bytes,
-                          s->d_extras));                                                            /* .c:94 */
+    LAUNCH(launch_aggregation(s, &s->paths, d_left));                                               /* .c:94 */
     mark(s, 3);
     LAUNCH(sum_and_wta(s, d_out, true));                                                            /* .c:94 sum, .c:99, .c:105 */
     if (s->keep_stages) LAUNCH(sgmd_d2d_async(dev, st, s->d_snap_wta, d_out, px_bytes));
     mark(s, 5);
-    if (o->is_check_lr) LAUNCH(sgmd_lrcheck(dev, st, g, d_out, s->d_disp_r, o->lrcheck_thres));     /* .c:109 */
+    LAUNCH(lr_stage(s, d_out));                                                                     /* .c:109 */
     if (s->keep_stages) LAUNCH(sgmd_d2d_async(dev, st, s->d_snap_lr, d_out, px_bytes));
     mark(s, 6);
     if (o->is_remove_speckles)                                                                      /* .c:115 */
@@ -648,15 +709,14 @@ static bool tile_aggregate(sgm_instance* s, int dir_mask, int run_anom)
     sgmd_paths p = s->paths;
     p.dir_mask = dir_mask;
     p.run_anom = run_anom;
-    return sgmd_aggregate(s->device, s->stream, &s->g, &p, s->tile_left, s->d_census_l, s->d_census_r, s->d_lut,
-                          s->d_planes, s->plane_bytes, s->d_extras) == 0;
+    return launch_aggregation(s, &p, s->tile_left) == 0;
 }
 
 bool sgm_tile_begin(sgm_instance* s, const uint8_t* d_left, const uint8_t* d_right)
 {
     if (!s || !s->initialized || !d_left || !d_right) return false;
     int rc = s->s_is_zero ? 0 : materialize_S(s);
-    if (rc == 0) rc = sgmd_census(s->device, s->stream, &s->g, d_left, d_right, s->d_census_l, s->d_census_r);
+    if (rc == 0) rc = prepare_costs(s, d_left, d_right);
     if (rc == 0 && s->need_plane_memset && s->paths.ndirs > 4)
         rc = sgmd_memset_async(s->device, s->stream, (char*)s->d_planes_alloc + 4 * s->plane_bytes, 0, 4 * s->plane_bytes);
     if (rc != 0) FAIL("a kernel launch failed");
@@ -709,10 +769,8 @@ bool sgm_tile_sweep(sgm_instance* s, int forward)
 bool sgm_tile_finish(sgm_instance* s, float* d_disp_left)
 {
     if (!s || !s->initialized || !s->tile_left || !d_disp_left) return false;
-    const sgmd_geom* g = &s->g;
-    const SGMOption* o = &s->opt;
     int rc = sum_and_wta(s, d_disp_left, false);
-    if (rc == 0 && o->is_check_lr) rc = sgmd_lrcheck(s->device, s->stream, g, d_disp_left, s->d_disp_r, o->lrcheck_thres);
+    if (rc == 0) rc = lr_stage(s, d_disp_left);
     s->tile_left = NULL;
     if (rc != 0) FAIL("a kernel launch failed");
     return true;
@@ -845,12 +903,12 @@ size_t sgm_read_stage(sgm_instance* s, int which, void* host_out, size_t capacit
     size_t elem = 0;
     bool volume = false;
     int row_a = 0, row_b = s->g.H;                                /* rows the device holds of a volume stage */
-    if ((which == 2 || which == 4 || which == 6 || which == 7) && !s->keep_stages) return 0;
+    if ((which == 4 || which == 6 || which == 7 || (which == 2 && !s->census_w)) && !s->keep_stages) return 0;
     if (which == 2 && !s->d_cost) return 0;
     if (which == 3 && (ensure_S(s) != 0 || materialize_S(s) != 0)) return 0;
     switch (which) {
-    case 0: src = (const char*)s->d_census_l + f * px * 4; elem = 4; break;
-    case 1: src = (const char*)s->d_census_r + f * px * 4; elem = 4; break;
+    case 0: src = s->census_w ? (const char*)s->d_census64_l + f * px * 8 : (const char*)s->d_census_l + f * px * 4; elem = s->census_w ? 8 : 4; break;
+    case 1: src = s->census_w ? (const char*)s->d_census64_r + f * px * 8 : (const char*)s->d_census_r + f * px * 4; elem = s->census_w ? 8 : 4; break;
     case 2: src = (const char*)s->d_cost + f * px * s->g.Dp; elem = 1; volume = true; break;
     case 3: src = (const char*)s->d_S + f * px * s->g.Dp * 2; elem = 2; volume = true; break;
     case 4: src = (const char*)s->d_snap_wta + f * px * 4; elem = 4; break;
@@ -911,6 +969,21 @@ bool SGM_SetDevice(int device_ordinal)
     return true;
 }
 
+static int g_default_census_w, g_default_census_h, g_default_view;
+
+bool SGM_SetCensusWindow(int width, int height)
+{
+    if (width < 1 || height < 1 || !(width & 1) || !(height & 1) || width * height > 64) return false;
+    g_default_census_w = width; g_default_census_h = height;
+    return g_default ? sgm_set_census_window(g_default, width, height) : true;
+}
+
+void SGM_SetReferenceView(int right)
+{
+    g_default_view = right ? 1 : 0;
+    if (g_default) sgm_set_reference_view(g_default, right);
+}
+
 void SGM_SetHonorNumPaths(int honor)
 {
     g_default_honor = honor;
@@ -927,6 +1000,8 @@ bool SGM_Initialize(uint16_t width, uint16_t height, const SGMOption* option)
         g_default = sgm_create(default_device());
         if (!g_default) return false;
         g_default->honor_num_paths = g_default_honor;
+        if (g_default_census_w) sgm_set_census_window(g_default, g_default_census_w, g_default_census_h);
+        sgm_set_reference_view(g_default, g_default_view);
     }
     return sgm_initialize(g_default, width, height, option);
 }

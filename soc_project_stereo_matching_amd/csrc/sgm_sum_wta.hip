@@ -457,6 +457,30 @@ __global__ __launch_bounds__(256) void sgm_lrcheck_k(float* __restrict__ dl, con
     }
 }
 
+// Extension: the mirror image of sgm_lrcheck_k with the right view as the reference view (out-of-place: the left map
+// is read at other columns of the row)
+__global__ __launch_bounds__(256) void sgm_lrcheck_right_k(const float* __restrict__ dr, const float* __restrict__ dl,
+                                                           float* __restrict__ out, int W, int H, float thres, int do_check, int row0)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = row0 + blockIdx.y;
+    if (x >= W) return;
+    const float inf = __builtin_inff();
+    const size_t fo = (size_t)blockIdx.z * W * H;
+    const size_t idx = fo + (size_t)y * W + x;
+    float d = dr[idx];
+    if (do_check && d != inf) {
+        const int xl = (int)((double)((float)x + d) + 0.5);
+        if (xl >= 0 && xl < W) {
+            const float l = dl[fo + (size_t)y * W + xl];
+            if (l != inf && fabs((double)(d - l)) > (double)thres) d = inf;
+        } else {
+            d = inf;
+        }
+    }
+    out[idx] = d;
+}
+
 template <int DPL, int THREADS>
 static void launch_sum_wta_lr(dim3 grid, hipStream_t st, const void* planes, size_t plane_bytes, int ndirs, const void* extras,
                               const void* row_extras, const void* row_extra_count, int row_cap, int accumulate, int store_S,
@@ -560,6 +584,17 @@ int sgmd_wta_right(int ord, void* stream, const sgmd_geom* g, const void* S, int
     dim3 grid((g->W + WTA_T - 1) / WTA_T, g->row_end - g->row_begin, g->B);
     hipLaunchKernelGGL(sgm_wta_right_k, grid, dim3(WTA_T), 0, (hipStream_t)stream, (const uint16_t*)S, (float*)disp_r,
                        g->W, g->H, g->D, g->Dp, g->dmin, check_unique, one_minus_ratio, g->row_begin);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int sgmd_lrcheck_right(int ord, void* stream, const sgmd_geom* g, const void* disp_r, const void* disp_l, float thres,
+                       int do_check, void* out)
+{
+    HIP_TRY(hipSetDevice(ord));
+    dim3 grid((g->W + 255) / 256, g->row_end - g->row_begin, g->B);
+    hipLaunchKernelGGL(sgm_lrcheck_right_k, grid, dim3(256), 0, (hipStream_t)stream, (const float*)disp_r, (const float*)disp_l,
+                       (float*)out, g->W, g->H, thres, do_check, g->row_begin);
     HIP_TRY(hipGetLastError());
     return 0;
 }

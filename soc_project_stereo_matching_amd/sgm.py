@@ -94,6 +94,12 @@ def load_library() -> C.CDLL:
     L.sgm_create.restype = C.c_void_p
     L.sgm_destroy.argtypes = [C.c_void_p]
     L.sgm_set_honor_num_paths.argtypes = [C.c_void_p, C.c_int]
+    L.sgm_set_census_window.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.sgm_set_census_window.restype = C.c_bool
+    L.sgm_set_reference_view.argtypes = [C.c_void_p, C.c_int]
+    L.SGM_SetCensusWindow.argtypes = [C.c_int, C.c_int]
+    L.SGM_SetCensusWindow.restype = C.c_bool
+    L.SGM_SetReferenceView.argtypes = [C.c_int]
     L.sgm_keep_stages.argtypes = [C.c_void_p, C.c_int]
     L.sgm_set_batch.argtypes = [C.c_void_p, C.c_int]
     L.sgm_set_batch.restype = C.c_bool
@@ -186,7 +192,9 @@ class _StageReader:
         """Copy one intermediate buffer of the last match to the host (parity tests)."""
         idx = STAGE_NAMES.index(which) if isinstance(which, str) else which
         h, w, d = self.shape
-        if idx >= 10:
+        if idx < 2 and getattr(self, "wide_census", False):
+            dt, shp = np.uint64, (h, w)
+        elif idx >= 10:
             dt, shp = np.uint8, (h, w, d)
         else:
             dt, shp = _STAGE_DTYPE[idx], ((h, w, d) if idx in (2, 3) else (h, w))
@@ -212,6 +220,15 @@ class SGM(_StageReader):
 
     def set_honor_num_paths(self, honor):
         self.lib.SGM_SetHonorNumPaths(int(honor))
+
+    def set_census_window(self, width: int, height: int) -> bool:
+        ok = bool(self.lib.SGM_SetCensusWindow(width, height))
+        if ok:
+            self.wide_census = not (width == 5 and height == 5)
+        return ok
+
+    def set_reference_view(self, right: bool):
+        self.lib.SGM_SetReferenceView(int(right))
 
     def keep_stages(self, enable=True):
         self.lib.SGM_KeepStages(int(enable))
@@ -304,6 +321,17 @@ class SGMInstance(_StageReader):
 
     def set_honor_num_paths(self, honor):
         self.lib.sgm_set_honor_num_paths(self.handle, int(honor))
+
+    def set_census_window(self, width: int, height: int) -> bool:
+        """Extension: odd census window of at most 64 pixels (5x5 = reference); next initialize/reset."""
+        ok = bool(self.lib.sgm_set_census_window(self.handle, width, height))
+        if ok:
+            self.wide_census = not (width == 5 and height == 5)
+        return ok
+
+    def set_reference_view(self, right: bool):
+        """Extension: True = the result is the right image's disparity map (mirrored LR check)."""
+        self.lib.sgm_set_reference_view(self.handle, int(right))
 
     def keep_stages(self, enable=True):
         self.lib.sgm_keep_stages(self.handle, int(enable))

@@ -62,6 +62,15 @@ int sgmd_census(int o, void* st, const sgmd_geom* g, const void* l, const void* 
 { (void)o; (void)st; (void)l; (void)r; (void)cl; (void)cr; return note("census", g->B); }
 int sgmd_cost(int o, void* st, const sgmd_geom* g, const void* cl, const void* cr, void* c)
 { (void)o; (void)st; (void)g; (void)cl; (void)cr; (void)c; return note("cost", 0); }
+int sgmd_census_window(int o, void* st, const sgmd_geom* g, int cw, int ch, const void* l, const void* r, void* cl, void* cr)
+{ (void)o; (void)st; (void)g; (void)l; (void)r; (void)cl; (void)cr; return note("census_window", cw * 100 + ch); }
+int sgmd_cost64(int o, void* st, const sgmd_geom* g, const void* cl, const void* cr, void* c)
+{ (void)o; (void)st; (void)g; (void)cl; (void)cr; (void)c; return note("cost64", 0); }
+int sgmd_aggregate_volume(int o, void* st, const sgmd_geom* g, const sgmd_paths* p, const void* img, const void* cost, const void* lut,
+                          void* planes, size_t pb, void* ex)
+{ (void)o; (void)st; (void)img; (void)cost; (void)lut; (void)planes; (void)pb; (void)ex; return note("aggregate_volume", p->dir_mask | (g->LPP << 8)); }
+int sgmd_lrcheck_right(int o, void* st, const sgmd_geom* g, const void* dr, const void* dl, float th, int chk, void* out)
+{ (void)o; (void)st; (void)g; (void)dr; (void)dl; (void)th; (void)out; return note("lrcheck_right", chk); }
 size_t sgmd_census_slack(const sgmd_geom* g) { return ((size_t)g->dmin + g->Dp + 8) * 4; }
 int sgmd_aggregate(int o, void* st, const sgmd_geom* g, const sgmd_paths* p, const void* img, const void* cl, const void* cr,
                    const void* lut, void* planes, size_t pb, void* ex)

@@ -215,3 +215,51 @@ def test_row_tile_instance_allocates_a_tile_not_a_frame(host):
     assert tile < 8 * cells_kib * 62 // 480 + 40 * w * h * 4 // 1024
     edge = allocated_kib((0, 60))
     assert edge <= tile
+
+
+def test_extension_options_select_their_stages(host):
+    """SURVEY.md 8(f)-4 extensions: a wide census window takes the materialised-cost path (u64 census, cost volume,
+    volume-fed aggregation with 16 lanes per pixel -- also for a batch, which otherwise uses 8); the right reference view
+    replaces LRCheck by its mirror image and needs the right-view WTA even with the LR check off."""
+    import soc_project_stereo_matching_amd as S
+    L = host
+    L.sgm_set_census_window.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.sgm_set_census_window.restype = C.c_bool
+    L.sgm_set_reference_view.argtypes = [C.c_void_p, C.c_int]
+    L.sgm_set_batch.argtypes = [C.c_void_p, C.c_int]
+    L.sgm_set_batch.restype = C.c_bool
+    f = Frame()
+    s = L.sgm_create(0)
+    assert not L.sgm_set_census_window(s, 9, 9) and not L.sgm_set_census_window(s, 6, 5) and not L.sgm_set_census_window(s, 0, 1)
+    assert L.sgm_set_census_window(s, 9, 7)
+    opt = S.default_option(16)
+    assert L.sgm_reset(s, 48, 20, C.byref(opt))
+    L.stub_clear()
+    assert L.sgm_match(s, *f.args())
+    assert log(L) == [("census_window", 907), ("cost64", 0), ("aggregate_volume", 0xFF | (16 << 8)), ("sum_wta_lr", 0), ("lrcheck", 0),
+                      ("speckle", 50), ("median", 0)]
+    assert L.sgm_set_census_window(s, 5, 5) and L.sgm_reset(s, 48, 20, C.byref(opt))     # back to the reference window
+    L.stub_clear()
+    assert L.sgm_match(s, *f.args())
+    assert [n for n, _ in log(L)][:2] == ["census", "aggregate"]
+    L.sgm_destroy(s)
+
+    s = L.sgm_create(0)
+    assert L.sgm_set_batch(s, 2) and L.sgm_set_census_window(s, 7, 7) and L.sgm_reset(s, 48, 20, C.byref(opt))
+    g = Frame(48, 40)                                                 # two frames back to back
+    L.stub_clear()
+    assert L.sgm_match(s, *g.args())
+    assert ("aggregate_volume", 0xFF | (16 << 8)) in log(L)
+    L.sgm_destroy(s)
+
+    for check_lr in (True, False):
+        s = L.sgm_create(0)
+        L.sgm_set_reference_view(s, 1)
+        o = S.default_option(16, is_check_lr=check_lr)
+        assert L.sgm_reset(s, 48, 20, C.byref(o))
+        L.stub_clear()
+        assert L.sgm_match(s, *f.args())
+        names = [n for n, _ in log(L, drop=("sync", "h2d", "d2h", "alloc", "memset", "d2d"))]
+        assert names == ["census", "aggregate", "sum_wta_lr", "lrcheck_right", "speckle", "median"]
+        assert ("lrcheck_right", int(check_lr)) in log(L)
+        L.sgm_destroy(s)
