@@ -7,7 +7,7 @@ One rocprofv3 run per counter set (FETCH_SIZE and WRITE_SIZE do not fit one pass
 only), each wrapping `python3 tools/pmc_workload.py`:
 
   * HBM traffic (FETCH_SIZE, WRITE_SIZE): one frame per launch with the batch kernels' lane configuration forced
-    (SGM_LANES_PER_PIXEL=8, SGM_HL=0) -- with 8 frames per launch these two counters under-read on this ROCm build
+    (SGM_LANES_PER_PIXEL=8, SGM_HL=0, SGM_SUM_SEGMENTS=1: whole rows in the fused sum kernel) -- with 8 frames per launch these two counters under-read on this ROCm build
     (~1/4 of the bytes, round 1), so traffic is taken per frame and scales with the frames of a launch.  FETCH_SIZE is
     doubled (gfx950 tallies 128-byte read requests as 64 bytes, /opt/skills/guides/MI355X_MICROARCH.md, HBM); both are KiB.
   * VALU issue (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_WAVE_CYCLES, SQ_BUSY_CYCLES, SQ_WAIT_INST_ANY, SQ_WAIT_ANY): 8
@@ -30,8 +30,8 @@ sys.path.insert(0, ROOT)
 from bench import WORKLOADS, source_id  # noqa: E402
 
 PASSES = [
-    ("fetch", ["FETCH_SIZE"], 1, {"SGM_LANES_PER_PIXEL": "8", "SGM_HL": "0"}),
-    ("write", ["WRITE_SIZE"], 1, {"SGM_LANES_PER_PIXEL": "8", "SGM_HL": "0"}),
+    ("fetch", ["FETCH_SIZE"], 1, {"SGM_LANES_PER_PIXEL": "8", "SGM_HL": "0", "SGM_SUM_SEGMENTS": "1"}),
+    ("write", ["WRITE_SIZE"], 1, {"SGM_LANES_PER_PIXEL": "8", "SGM_HL": "0", "SGM_SUM_SEGMENTS": "1"}),
     ("valu", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_WAVES"], 8, {}),
     ("lds", ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU"], 8, {}),
     ("grbm", ["GRBM_GUI_ACTIVE"], 8, {}),
@@ -52,7 +52,8 @@ def per_kernel(path):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="kitti_1242x375_d128_p8", choices=sorted(WORKLOADS))
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "counters.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "counters.json"),
+                    help="written under gpurun_out/ (the only directory that travels back from the GPU box); copy it to profiles/counters.json")
     ap.add_argument("--scratch", default=os.path.join(ROOT, "gpurun_out", "counters"))
     args = ap.parse_args()
     kernels = defaultdict(dict)
