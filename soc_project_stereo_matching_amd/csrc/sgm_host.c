@@ -496,6 +496,8 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
         sgmd_free(s->device, s->d_median_scratch);
         s->d_median_scratch = NULL;
         if (sgmd_alloc(s->device, &s->d_median_scratch, median_bytes) != 0) FAIL("device allocation failed (median scratch)");
+        /* the granule rows between the bands of a tall frame carry a generation tag: start from "never written" */
+        if (sgmd_memset_async(s->device, s->stream, s->d_median_scratch, 0, median_bytes) != 0) FAIL("clearing the median scratch failed");
         s->cap_median = median_bytes;
     }
     /* a Reset with unchanged shape and penalties (the per-frame case, Q14) re-uploads nothing */

@@ -248,9 +248,10 @@ static __device__ __forceinline__ void cswapf(float& a, float& b)
 static inline int med_tq(int W) { return ((W + MED_LAG + 4 * MED_PF - 1) / (4 * MED_PF)) * MED_PF; }
 
 __global__ __launch_bounds__(64) void sgm_median_prep_k(const float* __restrict__ disp, float4* __restrict__ P, int W, int H,
-                                                        int Tq)
+                                                        int Tq, int* __restrict__ ticket)
 {
     const int l = threadIdx.x, tq = blockIdx.x, g = blockIdx.y;
+    if (ticket && tq == 0 && g == 0 && l == 0) ticket[blockIdx.z] = 0;     // band tickets of the chained kernel (next in the stream)
     const int y = 1 + 64 * g + l;
     disp += (size_t)blockIdx.z * W * H;                                 // batch: z = frame
     P += (size_t)blockIdx.z * gridDim.y * Tq * MED_NE * 64;
@@ -432,6 +433,189 @@ __global__ __launch_bounds__(64 * MED_WAVES) void sgm_median_serial_k(const floa
     }
 }
 
+// Bands as a CHAIN of workgroups (frames taller than one band, e.g. 2160 rows): every band is a workgroup of its own on
+// its own CU, all bands of a frame run at the same time, skewed like the waves inside a band.  The last row of a band
+// reaches the band below through global memory as 8-byte granules {value, tag} -- one write-through (agent-scope)
+// store per column by the producing lane, polled with agent-scope loads by the consumer; the tag is a per-launch
+// generation number, so a granule is either this launch's value or not yet there, no fence and no flag needed
+// (MI355X_MICROARCH.md: data-tagged granules).  A granule row holds a whole image row: no back-pressure.  Bands are
+// handed out by an atomic ticket, so a band's producer has always started before its consumer (no reliance on the
+// dispatch order); polls are bounded.  One band after the other in one workgroup (the kernel above) took 3.9 ms at
+// 3840 x 2160; the chain takes the time of ONE skewed pass.
+#define MED_GPAD 256               // granule slots in front of column 0 (lane 63 runs 189 columns behind the time axis)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void sgm_median_chain_k(const float* __restrict__ disp, float4* __restrict__ P,
+                                                                 float4* __restrict__ O, unsigned long long* __restrict__ G,
+                                                                 int* __restrict__ ticket, unsigned long long* __restrict__ sink,
+                                                                 int W, int H, int Tq, unsigned gen)
+{
+#undef MED_WAVES
+#define MED_WAVES WAVES
+    __shared__ __attribute__((aligned(16))) float ring[MED_WAVES][MED_RING];
+    __shared__ int prog[MED_WAVES];      // last column the wave's lane 63 has put into its ring
+    __shared__ int cons[MED_WAVES];      // last column the wave has taken from the ring of the wave above
+    __shared__ float ring_dummy[64];
+    const int wv = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int rows = H - 2;
+    if (rows <= 0 || W <= 2) return;
+    const int groups = (rows + 63) / 64;
+    const int frame = blockIdx.y, nbands = gridDim.x;
+    disp += (size_t)frame * W * H;                                   // batch: y = frame
+    P += (size_t)frame * groups * Tq * MED_NE * 64;
+    O += (size_t)frame * groups * Tq * 64;
+    const int t_end = 4 * Tq;                                        // >= W + MED_LAG: lane 63 reaches column W-1 at t = W-1+MED_LAG
+    const int gstride = MED_GPAD + 4 * Tq + 64;                      // granules per band boundary
+    __shared__ int band_s;
+    if (threadIdx.x == 0) band_s = atomicAdd(&ticket[frame], 1);     // bands start in ticket order
+    __syncthreads();
+    const int band = band_s;
+    G += ((size_t)frame * nbands) * gstride;
+
+    {
+        const int gbase = band * MED_WAVES;
+        if (threadIdx.x < MED_WAVES) { prog[threadIdx.x] = 0; cons[threadIdx.x] = 0; }
+        __syncthreads();
+        const int g = gbase + wv;
+        if (g < groups) {                                            // wave-uniform
+            const int y = 1 + 64 * g + l;
+            const bool valid = y <= H - 2;
+            const bool feeds_next = (wv + 1 < MED_WAVES) && (g + 1 < groups);
+            const bool feeds_band = (wv + 1 == MED_WAVES) && (g + 1 < groups);   // this wave's last row goes to the band below
+            const bool top_from_band = (wv == 0) && (band > 0);
+            const bool top_from_ring = wv > 0;
+            // lane 63 of a band's last wave publishes its outputs as granules; everybody else writes to a sink
+            unsigned long long* const gout = (feeds_band && l == 63) ? G + (size_t)band * gstride + MED_GPAD
+                                                                     : sink + ((size_t)(frame * nbands + band) * 64 + l) * 4;
+            const unsigned long long* const gin = G + (size_t)(band > 0 ? band - 1 : 0) * gstride + MED_GPAD;
+            const bool publish = feeds_band && l == 63;
+            const int yr = valid ? y : H - 2;
+            float4* const Og = O + (size_t)g * Tq * 64 + l;
+            const float* const top_row = disp + (size_t)(yr - 1) * W;
+            const float4* Pg = P + (size_t)g * Tq * MED_NE * 64 + l;
+
+            float o1 = 0.f, o2 = 0.f;                                // own outputs of the last two steps
+            float T0 = 0.f;                                          // out(y-1, x-1)
+            float T1 = top_row[0];                                   // out(y-1, x): column 0 is border, never modified
+            asm volatile("" : "+v"(T1));                             // retire this load here, not at its first use inside the loop
+            __builtin_amdgcn_sched_barrier(0);
+            // pre-sorted neighbourhoods are read-only input: keep MED_PF batches (4 steps each) in flight
+            float4 evr[MED_PF][MED_NE];
+            auto load_batch = [&](float4 (&dst)[MED_NE], int t0) {
+                const int tq = min(t0 >> 2, Tq - 1);
+#pragma unroll
+                for (int k = 0; k < MED_NE; ++k) dst[k] = Pg[((size_t)tq * MED_NE + k) * 64];
+            };
+            // issue the prologue groups strictly in order: the loop's s_waitcnt counts are the minimum over the
+            // prologue path and the back edge, and vmcnt retires in issue order
+#pragma unroll
+            for (int u = 0; u < MED_PF; ++u) {
+                load_batch(evr[u], 4 * u);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+
+            // lane 63 feeds the next wave through the ring; every other lane writes to a dummy slot instead of
+            // branching (slots more than ~100 columns behind the consumer are free, so the out-of-range
+            // columns lane 63 writes before/after its row are harmless)
+            float* const ring_dst = (l == 63) ? &ring[wv][0] : &ring_dummy[l];
+            const unsigned ring_mask = (l == 63) ? (MED_RING - 1) : 0u;
+
+            auto run_batch = [&](const float4 (&ev)[MED_NE], int t0, const float (&tv)[4]) {
+                float res[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int x = t0 + j - MED_SKEW * l;
+                    const float e0 = (&ev[0].x)[j], e1 = (&ev[1].x)[j], e2 = (&ev[2].x)[j], e3 = (&ev[3].x)[j],
+                                e4 = (&ev[4].x)[j];
+                    // out(y-1, x+1): produced by the lane above two steps ago (its o2); lane 0 takes the top row
+                    const float b = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(tv[j]), __float_as_int(o2),
+                                                                               0x138 /* wave_shr:1 */, 0xF, 0xF, false));
+                    const float lo = fminf(fminf(T0, T1), b), hi = fmaxf(fmaxf(T0, T1), b);
+                    const float mid = __builtin_amdgcn_fmed3f(T0, T1, b);
+                    const float s3 = fmaxf(fmaxf(fminf(e3, lo), fminf(e2, mid)), fmaxf(fminf(e1, hi), e0));
+                    const float s4 = fmaxf(fmaxf(fminf(e4, lo), fminf(e3, mid)), fmaxf(fminf(e2, hi), e1));
+                    const float outv = __builtin_amdgcn_fmed3f(s3, o1, s4);   // border columns: s3 == s4 == original
+                    res[j] = outv;
+                    T0 = T1; T1 = b;
+                    o2 = o1; o1 = outv;
+                    ring_dst[(unsigned)(x - 1) & ring_mask] = outv;
+                }
+                // results go to the time-skewed, lane-interleaved buffer O (one coalesced 1 KiB store per batch;
+                // storing straight into the image would touch 64 different rows per instruction); the un-skew
+                // kernel moves them into the image afterwards
+                Og[(size_t)(t0 >> 2) * 64] = make_float4(res[0], res[1], res[2], res[3]);
+                if (feeds_band) {                                    // wave-uniform
+                    const int x0 = publish ? t0 - MED_SKEW * l : 0;  // column of res[0] (>= -MED_LAG: the pad in front takes it)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool real = publish && x0 + j >= 0 && x0 + j <= W - 1;
+                        const unsigned long long gr = (unsigned long long)__float_as_uint(res[j]) | ((unsigned long long)(real ? gen : 0u) << 32);
+                        __hip_atomic_store(gout + (publish ? x0 + j : j), gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            };
+
+            for (int tb = 0; tb < t_end; tb += 4 * MED_PF) {
+                // ---- flow control between waves, once per MED_PF batches (LDS only) ----
+                if (top_from_ring) {
+                    const int need = min(tb + 4 * MED_PF, W - 1);
+                    while (__hip_atomic_load(&prog[wv - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need)
+                        __builtin_amdgcn_s_sleep(1);
+                }
+                if (feeds_next) {
+                    const int last = tb + 4 * MED_PF - 1 - MED_LAG;  // last column lane 63 writes in this group
+                    while (__hip_atomic_load(&cons[wv + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < last - (MED_RING - 4 * MED_PF - 8))
+                        __builtin_amdgcn_s_sleep(1);
+                }
+                asm volatile("" ::: "memory");
+                float tvr[MED_PF][4];                                // lane 0: out(y-1, tb+1 .. tb+16)
+                if (top_from_band) {
+                    // the band above publishes its last row as granules: lanes 0..15 poll one column each
+                    const int col = min(tb + 1 + (l & 15), W - 1);
+                    unsigned long long gr = 0;
+                    for (int spin = 0; spin < (1 << 18); ++spin) {   // bounded: a lost producer must not hang the GPU
+                        gr = __hip_atomic_load(gin + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (__all((unsigned)(gr >> 32) == gen)) break;
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    const unsigned vbits = (unsigned)gr;
+#pragma unroll
+                    for (int u = 0; u < MED_PF; ++u)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) tvr[u][j] = __uint_as_float(__builtin_amdgcn_readlane(vbits, 4 * u + j));
+                }
+                if (top_from_ring) {
+#pragma unroll
+                    for (int u = 0; u < MED_PF; ++u) {
+                        const float4 r = *reinterpret_cast<const float4*>(&ring[wv - 1][(tb + 4 * u) & (MED_RING - 1)]);
+                        tvr[u][0] = r.x; tvr[u][1] = r.y; tvr[u][2] = r.z; tvr[u][3] = r.w;
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (l == 0) __hip_atomic_store(&cons[wv], tb + 4 * MED_PF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+#pragma unroll
+                for (int u = 0; u < MED_PF; ++u) {
+                    const int t0 = tb + 4 * u;
+                    if (!top_from_ring && !top_from_band) {
+                        // top of the frame: the row above comes with the pre-pass data (plane 5 of lane 0)
+                        tvr[u][0] = evr[u][5].x; tvr[u][1] = evr[u][5].y; tvr[u][2] = evr[u][5].z; tvr[u][3] = evr[u][5].w;
+                    }
+                    run_batch(evr[u], t0, tvr[u]);
+                    load_batch(evr[u], t0 + 4 * MED_PF);
+                }
+                if (feeds_next) {
+                    const int done = min(tb + 4 * MED_PF - 1 - MED_LAG, W - 1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (l == 63 && done >= 1) __hip_atomic_store(&prog[wv], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            if (l == 0) __hip_atomic_store(&cons[wv], 0x7FFFFFF0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+#undef MED_WAVES
+}
+#define MED_WAVES 8
+
+
 // results of the serial kernel: O[group][t/4][lane][t%4] with t = x + MED_SKEW*lane  ->  disp[y][x], interior only
 __global__ __launch_bounds__(256) void sgm_median_unskew_k(const float* __restrict__ O, float* __restrict__ disp, int W, int H,
                                                            int Tq)
@@ -477,11 +661,26 @@ int sgmd_speckle(int ord, void* stream, const sgmd_geom* g, void* disp, float di
     return 0;
 }
 
+// rows per band of the chained kernel: 4 waves (256 rows, one wave per SIMD of the band's CU)
+#define MED_CHAIN_WAVES 4
+static inline int med_chain(const sgmd_geom* g, int groups)
+{
+    static const int want = getenv("SGM_MEDIAN_CHAIN") ? atoi(getenv("SGM_MEDIAN_CHAIN")) : 1;   // 0: one band after the other
+    return want && groups > MED_WAVES;
+}
+static inline size_t med_granules(const sgmd_geom* g, int groups)      // granule rows + sink + tickets, in 8-byte words
+{
+    const int nbands = (groups + MED_CHAIN_WAVES - 1) / MED_CHAIN_WAVES;
+    const size_t gstride = MED_GPAD + 4 * (size_t)med_tq(g->W) + 64;
+    return (size_t)g->B * nbands * (gstride + 64 * 4) + (size_t)g->B + 8;
+}
+
 size_t sgmd_median_scratch_bytes(const sgmd_geom* g)
 {
     const int groups = (g->H - 2 + 63) / 64;
     if (groups <= 0) return 16;
-    return (size_t)g->B * groups * med_tq(g->W) * (MED_NE + 1) * 64 * sizeof(float4);   // inputs (MED_NE planes) + results
+    // inputs (MED_NE planes) + results, then (tall frames) the granule rows between bands
+    return (size_t)g->B * groups * med_tq(g->W) * (MED_NE + 1) * 64 * sizeof(float4) + med_granules(g, groups) * 8;
 }
 
 int sgmd_median(int ord, void* stream, const sgmd_geom* g, void* disp, void* scratch)
@@ -492,12 +691,27 @@ int sgmd_median(int ord, void* stream, const sgmd_geom* g, void* disp, void* scr
     const int groups = (rows + 63) / 64;
     const int Tq = med_tq(g->W);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(sgm_median_prep_k, dim3(Tq, groups, g->B), dim3(64), 0, st, (const float*)disp, (float4*)scratch, g->W,
-                       g->H, Tq);
-    const int waves = groups < MED_WAVES ? groups : MED_WAVES;
     float4* const results = (float4*)scratch + (size_t)g->B * groups * Tq * MED_NE * 64;
-    hipLaunchKernelGGL(sgm_median_serial_k, dim3(g->B), dim3(64 * waves), 0, st, (const float*)disp, (float4*)scratch, results,
-                       g->W, g->H, Tq);
+    unsigned long long* const G = (unsigned long long*)(results + (size_t)g->B * groups * Tq * 64);
+    const int nbands = (groups + MED_CHAIN_WAVES - 1) / MED_CHAIN_WAVES;
+    const size_t gstride = MED_GPAD + 4 * (size_t)Tq + 64;
+    unsigned long long* const sink = G + (size_t)g->B * nbands * gstride;
+    int* const ticket = (int*)(sink + (size_t)g->B * nbands * 64 * 4);
+    const bool chain = med_chain(g, groups);
+    hipLaunchKernelGGL(sgm_median_prep_k, dim3(Tq, groups, g->B), dim3(64), 0, st, (const float*)disp, (float4*)scratch, g->W,
+                       g->H, Tq, chain ? ticket : (int*)nullptr);
+    if (chain) {
+        // per-launch generation number of the granules (never 0; stale granules of earlier launches never match)
+        static unsigned generation = 0x5A5A0000u;
+        unsigned gen = __atomic_add_fetch(&generation, 1u, __ATOMIC_RELAXED);
+        if (gen == 0) gen = __atomic_add_fetch(&generation, 1u, __ATOMIC_RELAXED);
+        hipLaunchKernelGGL(sgm_median_chain_k<MED_CHAIN_WAVES>, dim3(nbands, g->B), dim3(64 * MED_CHAIN_WAVES), 0, st, (const float*)disp,
+                           (float4*)scratch, results, G, ticket, sink, g->W, g->H, Tq, gen);
+    } else {
+        const int waves = groups < MED_WAVES ? groups : MED_WAVES;
+        hipLaunchKernelGGL(sgm_median_serial_k, dim3(g->B), dim3(64 * waves), 0, st, (const float*)disp, (float4*)scratch, results,
+                           g->W, g->H, Tq);
+    }
     hipLaunchKernelGGL(sgm_median_unskew_k, dim3((g->W - 2 + 255) / 256, g->H - 2, g->B), dim3(256), 0, st,
                        (const float*)results, (float*)disp, g->W, g->H, Tq);
     HIP_TRY(hipGetLastError());

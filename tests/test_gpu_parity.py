@@ -651,3 +651,49 @@ def test_right_reference_view_extension(oracle, gsgm, shape, check_lr):
     # and back: the reference behaviour is untouched
     assert gsgm.reset(w, h, opt)
     assert_same(gsgm.match(left, right), oracle.run(left, right, opt)["final"], "left view again")
+
+
+@pytest.mark.parametrize("chain", ["1", "0"])
+@pytest.mark.parametrize("shape", [(64, 600), (300, 1500), (257, 2160), (1242, 515), (40, 4100)])
+def test_median_of_tall_frames(oracle, shape, chain, monkeypatch):
+    """Frames taller than one median band (8 waves x 64 rows): the bands run as a chain of workgroups that hand their last
+    row down through tagged granules in global memory (SGM_MEDIAN_CHAIN=1, default), or one after the other in one
+    workgroup (=0).  Crafted maps through the post-filter entry, twice on the same instance (the granule generation)."""
+    import torch
+    import soc_project_stereo_matching_amd as S
+    w, h = shape
+    monkeypatch.setenv("SGM_MEDIAN_CHAIN", chain)
+    rng = np.random.default_rng(w + h)
+    i = S.SGMInstance(0)
+    try:
+        opt = S.default_option(16, is_remove_speckles=False)
+        assert i.reset(w, h, opt)
+        maps = _speckle_maps(rng, h, w)
+        for name in ("ramp", "noise_thr", "holes", "blobs", "checker"):
+            m = maps[name]
+            want = oracle.median(m.copy())
+            for rep in range(2):
+                t = torch.from_numpy(m.copy()).cuda()
+                torch.cuda.synchronize()
+                assert i.tile_post(t.data_ptr()) and i.synchronize()
+                assert_same(t.cpu().numpy(), want, f"{name} {w}x{h} chain={chain} rep {rep}")
+    finally:
+        i.close()
+
+
+def test_tall_frames_in_a_batch(oracle):
+    """Chained median bands with several frames per launch (one band ticket counter per frame)."""
+    import soc_project_stereo_matching_amd as S
+    from oracle.pyoracle import default_option
+    w, h, d, B = 90, 700, 8, 3
+    opt = default_option(d, min_speckle_area=12)
+    frames = [oracle.synth_pair(w, h, d, 0x7A11 + k) for k in range(B)]
+    inst = S.SGMInstance(0, batch=B)
+    try:
+        assert inst.reset(w, h, opt)
+        for rep in range(2):
+            out = inst.match(np.stack([f[0] for f in frames]), np.stack([f[1] for f in frames]))
+            for k in range(B):
+                assert_same(out[k], oracle.run(frames[k][0], frames[k][1], opt)["final"], f"frame {k} rep {rep}")
+    finally:
+        inst.close()
