@@ -25,6 +25,10 @@ def run_tiles(args, init_dist, WORKLOADS, golden_digests):
     from .tiling import DeviceSlotEngine, TilePipeline, tile_rows
 
     world, rank, local_rank, backend = init_dist(args)
+    if world > 1:
+        # every rank takes part in one collective before the first (partial) point-to-point exchange of the pipeline
+        warm = torch.zeros(1, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(warm)
     w, h, d, seed = WORKLOADS[args.workload]
     opt = S.default_option(d)
     slots = max(world + 2, args.in_flight or 0)
