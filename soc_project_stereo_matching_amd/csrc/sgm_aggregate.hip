@@ -66,6 +66,15 @@ int sgmd_aggregate(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* 
     return aggregate_any(ord, stream, g, paths, img_left, census_l, census_r, nullptr, lut, planes, plane_bytes, extras);
 }
 
+/* diagnostics: shader-clock ticks and 100 MHz ticks over the lifetime of block 0 of the last aggregation launch (this TU's kernels) */
+int sgmd_debug_clock(int ord, unsigned long long out[2])
+{
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sgm_agg_clock), 2 * sizeof(unsigned long long)));
+    return 0;
+}
+
 int sgmd_aggregate_volume(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* paths, const void* img_left,
                           const void* cost, const void* lut, void* planes, size_t plane_bytes, void* extras)
 {

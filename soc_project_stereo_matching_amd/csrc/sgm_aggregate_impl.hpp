@@ -591,9 +591,24 @@ static __device__ __forceinline__ void agg_anomalous(const AggArgs& a, const Agg
 
 // NN: the step for non-negative P1 (agg_step_nn); the generic step only serves negative P1, for which the host
 // keeps to 16 lanes per pixel everywhere (sgm_host.c), so only those combinations are instantiated without NN
+// Diagnostics: the shader clock the launch runs at -- s_memtime (shader-clock ticks) against s_memrealtime (100 MHz) over the
+// lifetime of one long-running wave (block 0 = horizontal lines of frame 0: W-1 steps); read back with sgmd_debug_clock().
+// Two scalar loads per wave, nothing in the loops.
+__device__ unsigned long long g_sgm_agg_clock[2];
+
 template <int DPL, bool PAD, int LPP, int HL, bool NN, bool VOL = false>
 __global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
 {
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+    struct ClockProbe {
+        unsigned long long c0, r0;
+        __device__ ~ClockProbe() {
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                g_sgm_agg_clock[0] = __builtin_amdgcn_s_memtime() - c0;
+                g_sgm_agg_clock[1] = __builtin_amdgcn_s_memrealtime() - r0;
+            }
+        }
+    } probe{clk0, rt0};
     __shared__ unsigned short lut_s[256];
     __shared__ unsigned lut32_s[256];                        // the same penalties in both halves of a dword (packed u16 operand)
     const int lane = threadIdx.x;

@@ -132,6 +132,9 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
     constexpr int Dp = 16 * DPL;
     constexpr int LD = Dp + 2;
     constexpr int COLS = THREADS / 16;                                   // columns per iteration
+#ifdef SGM_SUM_PRIO
+    __builtin_amdgcn_s_setprio(SGM_SUM_PRIO);
+#endif
     constexpr int R = Dp + 2 * COLS;
     static_assert(R % COLS == 0, "a ring slot must always belong to the same px");
     __shared__ unsigned short ring[R * LD];

@@ -48,9 +48,12 @@ OP1(v_permlane32_swap,  "v_permlane32_swap_b32 %0, %1")
 OP1(ds_bpermute_b32,    "ds_bpermute_b32 %0, %1, %0\n s_waitcnt lgkmcnt(0)")
 OP1(ds_swizzle_b32,     "ds_swizzle_b32 %0, %0 offset:swizzle(SWAP,8)\n s_waitcnt lgkmcnt(0)")
 
+// shader clock held during the loop: s_memtime (shader-clock ticks) against s_memrealtime (100 MHz), MI355X_MICROARCH.md "DVFS"
+__device__ unsigned long long g_clk[2];
 template <class OP>
 __global__ __launch_bounds__(256) void k(unsigned* out, int iters, unsigned seed)
 {
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     unsigned a[8];
     for (int i = 0; i < 8; ++i) a[i] = seed * (threadIdx.x + 1) + i * 77;
     unsigned b = seed | 1, c = 0x06040200u ^ (seed & 1);
@@ -63,6 +66,10 @@ __global__ __launch_bounds__(256) void k(unsigned* out, int iters, unsigned seed
     unsigned s = 0;
     for (int i = 0; i < 8; ++i) s ^= a[i];
     out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) {
+        g_clk[0] = __builtin_amdgcn_s_memtime() - c0;
+        g_clk[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
 }
 
 template <class OP> int run()
@@ -73,7 +80,7 @@ template <class OP> int run()
     CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     printf("%-24s", OP::label);
     for (int wps : {8, 4, 2, 1}) {
-        const int iters = 2000, blocks = 256 * wps;           // wps blocks of 4 waves per CU -> wps waves per SIMD
+        const int iters = 20000, blocks = 256 * wps;           // wps blocks of 4 waves per CU -> wps waves per SIMD
         hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, 10, 12345u);
         CHK(hipDeviceSynchronize());
         CHK(hipEventRecord(e0));
@@ -82,10 +89,13 @@ template <class OP> int run()
         float ms;
         CHK(hipEventElapsedTime(&ms, e0, e1));
         const double winstr = (double)blocks * 4 * iters * 32;             // wave-instructions
-        const double simd_cycles = ms * 1e-3 * 2.4e9 * 1024;
-        printf("  %d waves/SIMD: %5.2f", wps, simd_cycles / winstr);
+        unsigned long long clk[2];
+        CHK(hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_clk), sizeof clk));
+        const double ghz = clk[1] ? (double)clk[0] / (double)clk[1] * 0.1 : 0.0;   // shader clock the loop ran at
+        const double simd_cycles = ms * 1e-3 * ghz * 1e9 * 1024;
+        printf("  %d w/SIMD: %5.2f @%.2f GHz", wps, simd_cycles / winstr, ghz);
     }
-    printf("   cycles per wave-instr per SIMD (at 2.4 GHz)\n");
+    printf("   cycles per wave-instr per SIMD at the measured shader clock\n");
     CHK(hipFree(d));
     return 0;
 }
