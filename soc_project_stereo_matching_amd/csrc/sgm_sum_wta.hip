@@ -101,15 +101,17 @@ __global__ __launch_bounds__(256) void sgm_sum_wta_k(const uint8_t* __restrict__
 //   ring: u16 [R][LD], R = Dp + 32 columns, LD = Dp + 2 (odd dword stride); entries of columns >= W and of
 //   padding disparities hold 65535 = the reference's "off the image" cost (ref :407).
 // ============================================================================================
+// a * b + c for a, b < 2^24: v_mad_u32_u24 (half rate); hipcc turns the plain 32-bit form into v_mad_u64_u32 / v_mul_lo_u32
+static __device__ __forceinline__ unsigned umad24(unsigned a, unsigned b, unsigned c) { return __umul24(a, b) + c; }
+
 template <int DPL, int STAGE>
-static __device__ __forceinline__ void sumlr_prefetch(CellVec<DPL> (&pre)[2][8], const uint8_t* planes, size_t plane_bytes,
-                                                      int ndirs, unsigned off)
+static __device__ __forceinline__ void sumlr_prefetch(CellVec<DPL> (&pre)[2][8], const uint8_t* const (&pb)[8], unsigned off)
 {
-    // always 8 unconditional loads (uniform plane base + 32-bit lane offset: no 64-bit address arithmetic per load) (see SLOW below): with four paths the upper four re-read planes 0..3 and are
-    // masked out when they are added
+    // always 8 unconditional loads (see SLOW below): with four paths the upper four re-read planes 0..3 and are masked out
+    // when they are added.  pb[] = the eight plane bases, computed once per workgroup (wave-uniform: SGPR pairs), so a load
+    // is base + zero-extended 32-bit lane offset with no 64-bit vector arithmetic
 #pragma unroll
-    for (int d = 0; d < 8; ++d)
-        load_cells_nt<DPL>(planes + (size_t)(d < ndirs ? d : d - 4) * plane_bytes + off, pre[STAGE][d]);
+    for (int d = 0; d < 8; ++d) load_cells_nt<DPL>(pb[d] + off, pre[STAGE][d]);
 }
 
 // SLOW = the variant that may read (accumulate) or write (store_S) S.  The common one has no conditional global
@@ -178,9 +180,12 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
         padpair[m] = ((sub * DPL + 2 * m >= D) ? 0xFFFFu : 0u) | ((sub * DPL + 2 * m + 1 >= D) ? 0xFFFF0000u : 0u);
 
     auto cell_off = [&](int x) { return row_cells + (unsigned)min(x, W - 1) * Dp + (unsigned)(sub * DPL); };
+    const uint8_t* pb[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) pb[d] = planes + (size_t)(d < ndirs ? d : d - 4) * plane_bytes;
     CellVec<DPL> pre[2][8];
-    sumlr_prefetch<DPL, 0>(pre, planes, plane_bytes, ndirs, cell_off(xa + px));
-    sumlr_prefetch<DPL, 1>(pre, planes, plane_bytes, ndirs, cell_off(xa + COLS + px));
+    sumlr_prefetch<DPL, 0>(pre, pb, cell_off(xa + px));
+    sumlr_prefetch<DPL, 1>(pre, pb, cell_off(xa + COLS + px));
 
     int slot = px;                                                       // ring slot of this thread's column: x mod R
 
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
             const int k = sub * DPL + i;
             int sl = base + k;
             if (sl >= R) sl -= R;
-            val[i] = ring[sl * LD + k];                                  // padding disparities hold 65535
+            val[i] = ring[umad24((unsigned)sl, (unsigned)LD, (unsigned)k)];   // padding disparities hold 65535
         }
 #pragma unroll
         for (int i = 0; i < DPL; ++i) {
@@ -236,8 +241,8 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
             st.m1 = kb >> 16;
             st.m2 = k2nd >> 16;
             st.d1 = (is_r && (kb >> 16) == 0xFFFFu) ? -1 : dbest;        // right view: nothing beat 65535 (ref :381, strict '>')
-            st.c1 = ring[sm * LD + km];
-            st.c2 = ring[sp * LD + kp];
+            st.c1 = ring[umad24((unsigned)sm, (unsigned)LD, (unsigned)km)];
+            st.c2 = ring[umad24((unsigned)sp, (unsigned)LD, (unsigned)kp)];
             st.pv = 0; st.want_next = false;
             float* const out = is_r ? disp_r + xr : disp_l + x;
             out[(size_t)row * W] = wta_finish(st, D, dmin, check_unique, one_minus_ratio);
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
 #pragma unroll
             for (int k = 0; k < NW; ++k) add_bytes(k, pre[STAGE][d].w[k], mask_lo, sel_hi);
         }
-        sumlr_prefetch<DPL, STAGE>(pre, planes, plane_bytes, ndirs, cell_off(x + 2 * COLS));     // columns of iteration it + 2
+        sumlr_prefetch<DPL, STAGE>(pre, pb, cell_off(x + 2 * COLS));     // columns of iteration it + 2
         for (int j = 0; j < n_extra; ++j) {
             if (ex_col[j] == x) {                                        // second visit of an anomalous line (LDS)
                 if constexpr (DPL == 2) {
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
         // (also without a right view: the left view fetches S[best +- 1] from here.  A column's slot is only ever
         // written by the wave that owns px = slot mod 16 -- R is a multiple of 16 -- so that read-back needs no barrier)
         {
-            unsigned* dst = reinterpret_cast<unsigned*>(&ring[slot * LD + sub * DPL]);
+            unsigned* dst = reinterpret_cast<unsigned*>(&ring[umad24((unsigned)slot, (unsigned)LD, (unsigned)(sub * DPL))]);
 #pragma unroll
             for (int m = 0; m < NPAIR; ++m) {
                 pr[m] = inside ? (pr[m] | padpair[m]) : 0xFFFFFFFFu;
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
     }
     // ---- columns past the image: only the right view is still working (no global loads) ----
     for (; it < n_iter; ++it) {
-        unsigned* dst = reinterpret_cast<unsigned*>(&ring[slot * LD + sub * DPL]);
+        unsigned* dst = reinterpret_cast<unsigned*>(&ring[umad24((unsigned)slot, (unsigned)LD, (unsigned)(sub * DPL))]);
 #pragma unroll
         for (int i = 0; i < DPL; i += 2) dst[i >> 1] = 0xFFFFFFFFu;
         finish_views(xa + it * COLS + px, false, 0u, 0u);
