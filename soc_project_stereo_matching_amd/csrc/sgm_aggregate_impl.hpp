@@ -1,6 +1,10 @@
 #pragma once
 #include "sgm_common.hpp"
 
+#ifndef SGM_AGG_PF
+#define SGM_AGG_PF 2      // steps of census words / grey values a wave keeps in flight (8- and 16-lane lines); 3 measured no faster
+#endif
+
 // ============================================================================================
 // path aggregation  (ref :198-372)
 //
@@ -256,7 +260,7 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
                                                    const unsigned* lut32_s, int dir, int grp)
 {
     constexpr int NP = DPL / 2;
-    constexpr int PF = (LPP >= 32) ? 4 : 2;                              // prefetch depth (steps): 2 keeps the 8-lines-per-wave kernel at 8 waves/SIMD; the latency-critical 32-lane lines look further ahead
+    constexpr int PF = (LPP >= 32) ? 4 : SGM_AGG_PF;                              // prefetch depth (steps): 2 keeps the 8-lines-per-wave kernel at 8 waves/SIMD; the latency-critical 32-lane lines look further ahead
     const int lane = threadIdx.x;
     const int dx = a.dx[dir], dy = a.dy[dir];
     const int W = a.W, H = a.H, Dp = a.Dp;
