@@ -108,6 +108,34 @@ def cpu_baseline(w, h, d, seed, budget_s=25.0):
             "fps": round(1.0 / t, 4)}
 
 
+def cpu_baseline_all_cores(w, h, d, seed, max_procs=16, timeout_s=90.0):
+    """Whole-host figure beside the one-core baseline: one independent process per available host core (at most 16 = a
+    one-GPU box's CPU share), each running tools/cpu_frame.py (one warm-up frame, one timed frame through the reference's C;
+    separate processes because the reference keeps its state in globals), all at once; throughput = processes / slowest
+    frame time.  Plain child processes with a wall-clock limit: this leg can fail, it cannot hang the bench."""
+    import subprocess
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    n = max(1, min(n, max_procs))
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "cpu_frame.py"), str(w), str(h), str(d)]
+    procs = [subprocess.Popen(cmd + [str(seed + k)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for k in range(n)]
+    deadline = time.perf_counter() + timeout_s
+    times = []
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=max(1.0, deadline - time.perf_counter()))
+            times.append(float(out.strip().splitlines()[-1]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    t = max(times)
+    return {"value": round(w * h * d * PATHS * n / t / 1e6, 2), "unit": "Mdisp/s", "cores": n, "fps": round(n / t, 3),
+            "sample": f"{n} processes x 1 frame of {w}x{h} D={d} at the same time (after a warm-up frame each); slowest {t:.2f} s"}
+
+
 def host_boundary(S, device, w, h, d, opt, pairs, B, digests, seeds, budget_s=6.0):
     """What a caller of the HOST-pointer boundary gets (PCIe inclusive; never `value`).
     blocking  = the reference contract: SGM_Reset + SGM_Match per frame on pageable arrays, one frame at a time.
@@ -445,6 +473,10 @@ def run_frames(args):
             line["host_boundary"] = hb
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(w, h, d, seed)
+            try:
+                cb["all_cores"] = cpu_baseline_all_cores(w, h, d, seed)
+            except Exception as e:                                   # the one-core figure is the contract; this one is extra
+                cb["all_cores"] = {"error": repr(e)}
             line["cpu_baseline"] = cb
             line["speedup_vs_cpu_baseline"] = round(value / cb["value"], 1)
         else:

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the GPU box (diagnostics; the committed parity tests are under tests/):
+random shapes / ranges / options / modes (batch, fused or separate kernels, row tiles, extensions) against the CPU oracle,
+every stage.  python tools/fuzz_parity.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import soc_project_stereo_matching_amd as S  # noqa: E402
+from oracle.pyoracle import STAGE_NAMES, Oracle, default_option  # noqa: E402
+
+
+def same(a, b):
+    return np.array_equal(a.view(np.uint32) if a.dtype == np.float32 else a, b.view(np.uint32) if b.dtype == np.float32 else b)
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+    orc = Oracle()
+    t0 = time.time()
+    n = bad = 0
+    while time.time() - t0 < budget:
+        w = int(rng.choice([rng.integers(6, 80), rng.integers(80, 700), rng.integers(700, 1400)], p=[0.3, 0.55, 0.15]))
+        h = int(rng.choice([rng.integers(6, 60), rng.integers(60, 400), rng.integers(514, 900)], p=[0.45, 0.45, 0.1]))
+        d = int(rng.choice([1, 3, 8, 16, 24, 40, 64, 100, 128, 160, 192, 256, 300]))
+        if w * h * d > 40e6:
+            continue
+        dmin = int(rng.choice([0, 0, 0, 2, 7]))
+        kw = dict(min_speckle_area=int(rng.choice([1, 9, 50, 300])), is_check_lr=bool(rng.random() < 0.8),
+                  is_check_unique=bool(rng.random() < 0.8), is_remove_speckles=bool(rng.random() < 0.8),
+                  p1=int(rng.choice([10, 0, 3, 40, 120])), p2_init=int(rng.choice([150, 0, 20, 90, 400])),
+                  uniqueness_ratio=float(rng.choice([0.99, 0.95, 0.8])), lrcheck_thres=float(rng.choice([1.0, 0.0, 2.5])))
+        opt = default_option(dmin + d, dmin, **kw)
+        seed = int(rng.integers(1, 2**31))
+        mode = str(rng.choice(["plain", "plain", "batch", "separate", "window", "rightview"]))
+        B = int(rng.integers(2, 5)) if mode == "batch" else 1
+        frames = [orc.synth_pair(w, h, d, seed + k) for k in range(B)]
+        if mode == "separate":
+            os.environ["SGM_FUSED_WTA"] = "0"
+        win = (5, 5)
+        if mode == "window":
+            win = [(7, 7), (9, 7), (3, 5), (7, 9), (1, 1), (63, 1)][int(rng.integers(0, 6))]
+        orc.set_census_window(*win)
+        orc.set_reference_view(mode == "rightview")
+        inst = S.SGMInstance(0, batch=B)
+        inst.set_census_window(*win)
+        inst.set_reference_view(mode == "rightview")
+        keep = bool(rng.random() < 0.5)
+        inst.keep_stages(keep)
+        try:
+            assert inst.reset(w, h, opt), "reset"
+            wants = [orc.run(l, r, opt) for l, r in frames]
+            L = np.stack([f[0] for f in frames]) if B > 1 else frames[0][0]
+            R = np.stack([f[1] for f in frames]) if B > 1 else frames[0][1]
+            out = inst.match(L, R)
+            assert out is not None, "match"
+            diffs = []
+            for k in range(B):
+                got_final = out[k] if B > 1 else out
+                if not same(got_final, wants[k]["final"]):
+                    diffs.append(f"frame {k} final")
+                inst.select_frame(k)
+                stages = STAGE_NAMES if keep else ["census_l", "census_r", "aggr", "final"] + (["disp_r"] if (opt.is_check_lr or mode == "rightview") else [])
+                for name in stages:
+                    if name == "disp_r" and not (opt.is_check_lr or mode == "rightview"):
+                        continue
+                    if not same(inst.read_stage(name), wants[k][name]):
+                        diffs.append(f"frame {k} {name}")
+            n += 1
+            if diffs:
+                bad += 1
+                print(f"MISMATCH {w}x{h} d=[{dmin},{dmin + d}) mode={mode} B={B} win={win} keep={keep} seed={seed} opts={kw}: {diffs[:6]}", flush=True)
+        finally:
+            inst.close()
+            os.environ.pop("SGM_FUSED_WTA", None)
+            orc.set_census_window(5, 5)
+            orc.set_reference_view(False)
+        if n % 20 == 0:
+            print(f"{n} cases, {bad} mismatching, {time.time() - t0:.0f} s", flush=True)
+    print(f"done: {n} cases, {bad} mismatching")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
