@@ -252,3 +252,15 @@ def test_three_rank_pipeline_with_frames_in_flight(tmp_path, oracle):
     for k in range(n):
         l, r = oracle.synth_pair(w, h, d, seed + k)
         assert_same(np.load(out + f".{k}.npy"), oracle.run(l, r, default_option(d))["final"], f"frame {k}")
+
+
+def test_rccl_grouped_exchange_on_one_gpu():
+    """The RCCL code path of DeviceSlotEngine.exchange -- P2POp list, ONE grouped batch_isend_irecv, work.wait() under the
+    communication stream, HIP events against the slots' own streams -- with the only RCCL point-to-point a single GPU can
+    do: a world-size-1 nccl group whose rank sends to and receives from itself (tools/nccl_self_exchange.py, in a process of
+    its own so that the process group does not leak into the test session).  Not the xGMI transport."""
+    import subprocess
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "nccl_self_exchange.py")], capture_output=True, text=True,
+                       timeout=300, env=dict(os.environ, MASTER_PORT=str(_free_port())))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "nccl self-exchange ok" in p.stdout
