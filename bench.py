@@ -233,15 +233,18 @@ def load_counters(workload):
 
 
 def kernel_roofline(kernel, ms, launches, min_ms, B, counters, alg_bytes_per_frame, alg_note, ref_equiv_bytes_per_frame=None):
-    """roofline object of one kernel: `achieved` = algorithmic bytes of THIS dataflow per launch / mean launch time
-    (HIP events over the timed region); `traffic` = HBM bytes per launch from the PMC passes; `valu` = share of the chip's
-    VALU issue slots the launch's wave-level VALU instructions take.  `bound` names the larger of the two fractions."""
+    """roofline object of one kernel.  `achieved` / `frac` = HBM bytes the launch really moves (`traffic`, from the PMC passes
+    of profiles/counters.json) / mean launch time (HIP events over the timed region) against the 8 TB/s peak; where no fresh
+    counters exist they fall back to the bytes this dataflow has to move (`algorithmic_*`, always reported beside them).
+    `valu` = share of the chip's VALU issue slots the launch's wave-level VALU instructions take.  `bound` names the larger
+    of the two fractions."""
     t = ms * 1e-3
     alg = alg_bytes_per_frame * B
     r = {"bound": "hbm", "kernel": kernel, "achieved": round(alg / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-         "frac": round(alg / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "avg_launch_ms": round(ms, 4),
+         "frac": round(alg / t / 1e9 / HBM_PEAK_GBS, 4), "bytes_used": "algorithmic", "traffic": None, "avg_launch_ms": round(ms, 4),
          "min_launch_ms": round(min_ms, 4), "launches_timed": launches, "frames_per_launch": B,
-         "algorithmic_bytes_per_launch": int(alg), "algorithmic_bytes": alg_note}
+         "algorithmic_bytes_per_launch": int(alg), "algorithmic_bytes": alg_note,
+         "algorithmic_GBps": round(alg / t / 1e9, 1), "algorithmic_frac": round(alg / t / 1e9 / HBM_PEAK_GBS, 4)}
     if counters:
         k = counters.get("kernels", {}).get(kernel)
         stale = counters.get("source_id") != source_id()
@@ -250,14 +253,16 @@ def kernel_roofline(kernel, ms, launches, min_ms, B, counters, alg_bytes_per_fra
         if k:
             if k.get("hbm_bytes_per_frame") is not None:
                 r["traffic"] = int(k["hbm_bytes_per_frame"] * B)
-                r["traffic_GBps"] = round(r["traffic"] / t / 1e9, 1)
-                r["traffic_frac"] = round(r["traffic"] / t / 1e9 / HBM_PEAK_GBS, 4)
+                if not stale:
+                    r["achieved"] = round(r["traffic"] / t / 1e9, 1)
+                    r["frac"] = round(r["traffic"] / t / 1e9 / HBM_PEAK_GBS, 4)
+                    r["bytes_used"] = "measured traffic (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/counters.json)"
             if k.get("valu_insts_per_frame") is not None:
                 insts = k["valu_insts_per_frame"] * B
                 vfrac = insts * VALU_ISSUE_CYCLES / (N_SIMD * CLOCK_HZ * t)
                 r["valu"] = {"wave_insts_per_launch": int(insts), "issue_cycles_per_inst": VALU_ISSUE_CYCLES,
                              "frac": round(vfrac, 4), "of": f"{N_SIMD} SIMDs x {CLOCK_HZ / 1e9:.1f} GHz"}
-                if vfrac > (r.get("traffic_frac") or r["frac"]):
+                if vfrac > r["frac"]:
                     r["bound"] = "valu"
     if ref_equiv_bytes_per_frame:
         eq = ref_equiv_bytes_per_frame * B / t / 1e9

@@ -179,6 +179,9 @@ class ToySlotEngine:
 
     def post(self, slot):
         assert (self.maps[slot] != -7).all(), "a row of another rank never arrived"
+        # owners finish their frames at different speeds: frames then complete out of order across the ranks
+        import time
+        time.sleep(0.004 * ((slot * 5 + self.rows[0]) % 3))
         self.maps[slot] += 1
         self.log.append(("post", slot))
 
@@ -211,9 +214,11 @@ def _pipe_worker(rank, world, port, h, w, n_frames, out_path):
     eng = ToySlotEngine(h, w, tile_rows(h, world)[rank], world + 2)
     pipe = TilePipeline(eng, rank, world, h, dist=dist)
     got = {}
+    import time
     for rep in range(2):                                            # the pipeline object is reusable
         pipe.run(n_frames, lambda f: (torch.from_numpy(l) + f, torch.from_numpy(r)),
-                 lambda f, t, ev: got.__setitem__((rep, f), t.clone()))
+                 lambda f, t, ev: (got.__setitem__((rep, f), t.clone()),
+                                   open(f"{out_path}.order", "a").write(f"{rep} {f} {time.time():.6f}\n")))
     for (rep, f), t in got.items():
         assert f % world == rank                                    # only a frame's owner runs its post pass
         np.save(f"{out_path}.rep{rep}.f{f}.npy", t.numpy())
@@ -239,6 +244,10 @@ def test_frames_in_flight_pipeline_over_gloo(tmp_path, world, n_frames):
         want = match_tiled(ToyEngine(h, w, (0, h)), 0, 1, torch.from_numpy(l) + f, torch.from_numpy(r), h).numpy()
         for rep in range(2):
             assert np.array_equal(np.load(f"{out}.rep{rep}.f{f}.npy"), want), (rep, f)
+    # every frame of every run was delivered exactly once (the owners' post passes take different times, so the wall-clock
+    # order of completion across ranks is not the frame order; results are keyed by frame, not by arrival)
+    done = [tuple(int(v) for v in line.split()[:2]) for line in open(f"{out}.order")]
+    assert sorted(done) == [(rep, f) for rep in range(2) for f in range(n_frames)]
 
 
 def test_pipeline_single_rank_and_slot_guard():
