@@ -392,6 +392,19 @@ def run_frames(args):
             stage_min[name] = min(stage_min.get(name, 1e30), mn[name])
     stage_ms = {k: v / launches for k, v in stage_sum.items()} if launches else {}
 
+    # the same batches with ONE instance and nothing else on the GPU (after the timed region): the kernels' own launch times,
+    # without a second batch competing for VALU issue and HBM
+    alone_ms = {}
+    if n_inst > 1:
+        for rep in range(2):                             # a first pass to settle, the second one is read
+            insts[0].enable_timing(True)
+            for k in range(10):
+                l, r = frames[k % n_frames]
+                if not (insts[0].reset(w, h, opt) and insts[0].match_device(l.data_ptr(), r.data_ptr(), outs[0].data_ptr())):
+                    raise RuntimeError("sgm_match_device failed")
+            insts[0].synchronize()
+        alone_ms = insts[0].mean_timing()[0]
+
     # single-frame latency: one batch-1 instance, nothing else in flight, after the timed region (its own output buffer)
     solo = S.SGMInstance(local_rank)
     solo_out = torch.empty((h, w), dtype=torch.float32, device="cuda")
@@ -435,6 +448,17 @@ def run_frames(args):
             sum_roofline = kernel_roofline("sgm_sum_wta_lr_k", stage_ms["sum"], launches, stage_min["sum"], B, counters,
                                            w * h * dp * 8 + w * h * 8,
                                            "W*H*Dp*8 (eight planes read once) + W*H*8 (two disparity maps written)")
+        # ... and the same two objects for the launch times with the GPU to itself
+        for rf, key in ((roofline, "aggregate"), (sum_roofline, "sum")):
+            if rf and alone_ms.get(key):
+                ta = alone_ms[key] * 1e-3
+                alone = {"avg_launch_ms": round(alone_ms[key], 4), "batches_in_flight": 1}
+                if rf.get("traffic"):
+                    alone["frac"] = round(rf["traffic"] / ta / 1e9 / HBM_PEAK_GBS, 4)
+                alone["algorithmic_frac"] = round(rf["algorithmic_bytes_per_launch"] / ta / 1e9 / HBM_PEAK_GBS, 4)
+                if rf.get("valu"):
+                    alone["valu_frac"] = round(rf["valu"]["wave_insts_per_launch"] * VALU_ISSUE_CYCLES / (N_SIMD * CLOCK_HZ * ta), 4)
+                rf["alone"] = alone
         frame_bytes = cells * (5 * PATHS + 3)
         steps_frames = args.steps * B
         line = {
