@@ -171,6 +171,19 @@ bool   sgm_tile_export_boundary(sgm_instance* s, int forward, void* d_buf);
 bool   sgm_tile_finish(sgm_instance* s, float* d_disp_left);
 bool   sgm_tile_post(sgm_instance* s, float* d_disp_left);
 
+/* ---- test-platform arithmetic on device buffers ----
+ * What the reference's host platform does with a returned map (HostScript_Server/depth_image.py:138-165 disparity_to_depth,
+ * :276-319 compare_img), for maps that are already in HBM.  Restated from reading: that module imports cv2, which is not
+ * installed where this library is built, so no reference-made vectors exist -- "parity unpinned" (tests compare with the
+ * host restatement soc_project_stereo_matching_amd/platform.py).
+ *   depth[mm] = float32(fx * baseline) / (disparity + doffs); a non-finite or zero denominator (invalid = +INF) -> NaN.
+ *   compare (blocking): over the pixels finite in BOTH images: rmse = sqrt(mean((test - gt)^2)), bad_pixel_rate = share
+ *   with |test - gt| > abs_thresh [mm], n_valid; (NaN, NaN, 0) if there is none.  Asynchronous / blocking on sgm_stream(s). */
+bool   sgm_disparity_to_depth(sgm_instance* s, const float* d_disparity, size_t count, float fx, float baseline, float doffs,
+                              float* d_depth);
+bool   sgm_compare_depth(sgm_instance* s, const float* d_ground_truth, const float* d_test, size_t count, float abs_thresh,
+                         double* rmse, double* bad_pixel_rate, uint64_t* n_valid);
+
 /* ---- stage read-back (parity tests; copies device -> host, blocking) ----
  * which: 0 census left (u32 [H][W])       1 census right (u32 [H][W])    (u64 words with a wide census window)
  *        2 matching cost (u8 [H][W][D])   3 aggregated cost S (u16 [H][W][D])

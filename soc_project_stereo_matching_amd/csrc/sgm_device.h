@@ -134,6 +134,12 @@ int sgmd_speckle(int ord, void* stream, const sgmd_geom* g, void* disp, float di
 size_t sgmd_median_scratch_bytes(const sgmd_geom* g);
 int sgmd_median(int ord, void* stream, const sgmd_geom* g, void* disp, void* scratch);
 
+/* SURVEY.md 8f-3 on device buffers: depth[mm] = float32(fx * baseline) / (disparity + doffs), NaN where the denominator is not
+ * finite or zero; and (blocking) the sums behind RMSE / bad-pixel rate over the pixels finite in both depth images */
+int sgmd_depth(int ord, void* stream, const void* disp, size_t n, float fx, float baseline, float doffs, void* depth);
+int sgmd_score(int ord, void* stream, const void* ground_truth, const void* test, size_t n, float abs_thresh, double* sum_sq,
+               unsigned long long* n_valid, unsigned long long* n_bad);
+
 #ifdef __cplusplus
 }
 #endif

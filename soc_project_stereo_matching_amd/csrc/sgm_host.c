@@ -884,6 +884,29 @@ void* sgm_host_alloc(sgm_instance* s, size_t bytes)
 }
 void sgm_host_free(sgm_instance* s, void* p) { if (s && p) sgmd_free_pinned(s->device, p); }
 
+/* ------------------------------------------------------------------ test-platform arithmetic on device buffers (8f-3) */
+
+bool sgm_disparity_to_depth(sgm_instance* s, const float* d_disparity, size_t count, float fx, float baseline, float doffs,
+                            float* d_depth)
+{
+    if (!s || !d_disparity || !d_depth) return false;
+    return sgmd_depth(s->device, s->stream, d_disparity, count, fx, baseline, doffs, d_depth) == 0;
+}
+
+bool sgm_compare_depth(sgm_instance* s, const float* d_ground_truth, const float* d_test, size_t count, float abs_thresh,
+                       double* rmse, double* bad_pixel_rate, uint64_t* n_valid)
+{
+    if (!s || !d_ground_truth || !d_test) return false;
+    double sumsq = 0.0;
+    unsigned long long n = 0, bad = 0;
+    if (sgmd_score(s->device, s->stream, d_ground_truth, d_test, count, abs_thresh, &sumsq, &n, &bad) != 0) return false;
+    if (n_valid) *n_valid = n;
+    /* depth_image.py:306-308: (nan, nan, 0) when no pixel is finite in both images */
+    if (rmse) *rmse = n ? sqrt(sumsq / (double)n) : NAN;
+    if (bad_pixel_rate) *bad_pixel_rate = n ? (double)bad / (double)n : NAN;
+    return true;
+}
+
 /* ------------------------------------------------------------------ stage read-back */
 
 static size_t compact_volume(const sgm_instance* s, const void* padded, size_t elem, void* out)

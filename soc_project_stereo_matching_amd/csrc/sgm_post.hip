@@ -632,7 +632,102 @@ __global__ __launch_bounds__(256) void sgm_median_unskew_k(const float* __restri
 }
 
 
+// ============================================================================================
+// Test-platform arithmetic next to the hot path, on device buffers: disparity -> depth in mm and the
+// scores the reference's server computes for a returned depth image (HostScript_Server/depth_image.py:138-165, 276-319;
+// restated from reading -- that module imports cv2, so no reference vectors exist: "parity unpinned").
+// ============================================================================================
+
+// (this translation unit is compiled with -fno-honor-nans: the hot path has no NaN.  These two kernels do see NaN, so they
+// test and make it with integer operations on the bit patterns, which no floating-point option can fold away)
+static __device__ __forceinline__ bool finite_bits(float v) { return (__float_as_uint(v) & 0x7F800000u) != 0x7F800000u; }
+
+// depth = float32(fx * baseline) / (disparity + doffs); a non-finite or zero denominator (invalid disparity = +INF) gives NaN
+__global__ __launch_bounds__(256) void sgm_depth_k(const float* __restrict__ disp, float* __restrict__ depth, size_t n, float fb,
+                                                   float doffs)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float denom = disp[i] + doffs;
+    const bool ok = finite_bits(denom) && (__float_as_uint(denom) << 1) != 0u;      // finite and not +-0
+    depth[i] = ok ? fb / denom : __uint_as_float(0x7FC00000u);
+}
+
+// per-block partial sums over the pixels finite in both images: sum of squared differences (double), count, count of
+// |difference| > abs_thresh; the host adds the partials in block order (deterministic)
+struct ScorePartial { double sumsq; unsigned long long n, bad; };
+#define SCORE_PER_THREAD 16
+__global__ __launch_bounds__(256) void sgm_score_k(const float* __restrict__ gt, const float* __restrict__ test, size_t n,
+                                                   float abs_thresh, ScorePartial* __restrict__ out)
+{
+    __shared__ double s_sum[256];
+    __shared__ unsigned s_n[256], s_bad[256];
+    double sum = 0.0;
+    unsigned cnt = 0, bad = 0;
+    const size_t base = (size_t)blockIdx.x * 256 * SCORE_PER_THREAD + threadIdx.x;
+    for (int k = 0; k < SCORE_PER_THREAD; ++k) {
+        const size_t i = base + (size_t)k * 256;
+        if (i < n) {
+            const float a = test[i], b = gt[i];
+            if (finite_bits(a) && finite_bits(b)) {
+                const float diff = a - b;                            // float32, as numpy on float32 arrays
+                sum += (double)diff * (double)diff;
+                ++cnt;
+                bad += fabsf(diff) > abs_thresh;
+            }
+        }
+    }
+    s_sum[threadIdx.x] = sum; s_n[threadIdx.x] = cnt; s_bad[threadIdx.x] = bad;
+    __syncthreads();
+    for (int step = 128; step > 0; step >>= 1) {
+        if ((int)threadIdx.x < step) {
+            s_sum[threadIdx.x] += s_sum[threadIdx.x + step];
+            s_n[threadIdx.x] += s_n[threadIdx.x + step];
+            s_bad[threadIdx.x] += s_bad[threadIdx.x + step];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[blockIdx.x].sumsq = s_sum[0]; out[blockIdx.x].n = s_n[0]; out[blockIdx.x].bad = s_bad[0]; }
+}
+
+
 extern "C" {
+
+int sgmd_depth(int ord, void* stream, const void* disp, size_t n, float fx, float baseline, float doffs, void* depth)
+{
+    HIP_TRY(hipSetDevice(ord));
+    if (n == 0) return 0;
+    const float fb = (float)((double)fx * (double)baseline);
+    hipLaunchKernelGGL(sgm_depth_k, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)disp,
+                       (float*)depth, n, fb, doffs);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+/* blocking: launches the reduction, copies the per-block partials back and adds them in block order */
+int sgmd_score(int ord, void* stream, const void* gt, const void* test, size_t n, float abs_thresh, double* sumsq,
+               unsigned long long* n_valid, unsigned long long* n_bad)
+{
+    HIP_TRY(hipSetDevice(ord));
+    *sumsq = 0.0; *n_valid = 0; *n_bad = 0;
+    if (n == 0) return 0;
+    const size_t per_block = 256 * SCORE_PER_THREAD;
+    const unsigned blocks = (unsigned)((n + per_block - 1) / per_block);
+    ScorePartial* d_part = nullptr;
+    HIP_TRY(hipMalloc(&d_part, sizeof(ScorePartial) * blocks));
+    hipLaunchKernelGGL(sgm_score_k, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)gt, (const float*)test, n,
+                       abs_thresh, d_part);
+    ScorePartial* h = new ScorePartial[blocks];
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(h, d_part, sizeof(ScorePartial) * blocks, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e == hipSuccess)
+        for (unsigned b = 0; b < blocks; ++b) { *sumsq += h[b].sumsq; *n_valid += h[b].n; *n_bad += h[b].bad; }
+    delete[] h;
+    (void)hipFree(d_part);
+    HIP_TRY(e);
+    return 0;
+}
 
 int sgmd_speckle(int ord, void* stream, const sgmd_geom* g, void* disp, float diff, unsigned min_area, void* labels,
                  void* sizes, void* totals)

@@ -143,6 +143,11 @@ def load_library() -> C.CDLL:
     L.sgm_mean_timing.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
                                   C.POINTER(C.c_long)]
     L.sgm_mean_timing.restype = C.c_int
+    L.sgm_disparity_to_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_void_p]
+    L.sgm_disparity_to_depth.restype = C.c_bool
+    L.sgm_compare_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.POINTER(C.c_double),
+                                    C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.sgm_compare_depth.restype = C.c_bool
     L.sgm_host_walk_line.argtypes = [C.c_int] * 5 + [C.c_void_p]
     L.sgm_host_walk_line.restype = C.c_int
     L.sgm_host_anomalous_line.argtypes = [C.c_int, C.c_int]
@@ -435,6 +440,16 @@ class SGMInstance(_StageReader):
 
     def tile_post(self, d_disp: int) -> bool:
         return bool(self.lib.sgm_tile_post(self.handle, d_disp))
+
+    # ---- test-platform arithmetic on device buffers (include/sgm_mi355x.h) ----
+    def disparity_to_depth(self, d_disp: int, count: int, fx: float, baseline: float, doffs: float, d_depth: int) -> bool:
+        return bool(self.lib.sgm_disparity_to_depth(self.handle, d_disp, count, fx, baseline, doffs, d_depth))
+
+    def compare_depth(self, d_ground_truth: int, d_test: int, count: int, abs_thresh: float = 10.0):
+        """(rmse, bad_pixel_rate, n_valid) of two device depth images; None where the C call returns false."""
+        rmse, bpr, n = C.c_double(), C.c_double(), C.c_uint64()
+        ok = self.lib.sgm_compare_depth(self.handle, d_ground_truth, d_test, count, abs_thresh, C.byref(rmse), C.byref(bpr), C.byref(n))
+        return (rmse.value, bpr.value, int(n.value)) if ok else None
 
     @property
     def stream(self) -> int:

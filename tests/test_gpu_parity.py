@@ -697,3 +697,49 @@ def test_tall_frames_in_a_batch(oracle):
                 assert_same(out[k], oracle.run(frames[k][0], frames[k][1], opt)["final"], f"frame {k} rep {rep}")
     finally:
         inst.close()
+
+
+def test_depth_and_scoring_on_device(oracle):
+    """SURVEY.md 8(f)-3 on device buffers: disparity -> depth in mm and RMSE / bad-pixel rate / valid count, against the host
+    restatement soc_project_stereo_matching_amd/platform.py (the reference's depth_image.py imports cv2, which is not
+    installed: no reference-made vectors, "parity unpinned").  Depth: bit-exact (one float32 divide).  Scores: counts exact,
+    rmse within 1e-6 relative (numpy sums float32 squares pairwise, the device sums doubles in block order)."""
+    import torch
+    import soc_project_stereo_matching_amd as S
+    from soc_project_stereo_matching_amd.platform import compare_depth, disparity_to_depth
+    w, h, d = 640, 200, 64
+    left, right = oracle.synth_pair(w, h, d, 0xDE97)
+    inst = S.SGMInstance(0)
+    try:
+        assert inst.reset(w, h, S.default_option(d))
+        disp = inst.match(left, right)                               # +inf where invalid
+        fx, baseline, doffs = 3979.911, 193.001, 124.343             # a Middlebury calib.txt's magnitudes
+        t_disp = torch.from_numpy(disp).cuda()
+        t_depth = torch.empty_like(t_disp)
+        torch.cuda.synchronize()
+        assert inst.disparity_to_depth(t_disp.data_ptr(), disp.size, fx, baseline, doffs, t_depth.data_ptr()) and inst.synchronize()
+        got = t_depth.cpu().numpy()
+        want = disparity_to_depth(disp, fx, baseline, doffs)
+        assert np.array_equal(np.isnan(got), np.isnan(want)) and int(np.isnan(want).sum()) > 0
+        ok = ~np.isnan(want)
+        assert np.array_equal(got[ok].view(np.uint32), want[ok].view(np.uint32))
+        # a denominator of exactly zero and a NaN disparity also give NaN
+        odd = torch.tensor([-doffs, float("nan"), float("inf"), 10.0], dtype=torch.float32).cuda()
+        out = torch.empty_like(odd)
+        assert inst.disparity_to_depth(odd.data_ptr(), 4, fx, baseline, float(np.float32(doffs)), out.data_ptr()) and inst.synchronize()
+        assert torch.isnan(out[:3]).all() and torch.isfinite(out[3])
+        # scoring against a perturbed "ground truth" with holes
+        rng = np.random.default_rng(5)
+        gt = (want + rng.normal(0, 8, want.shape).astype(np.float32)).astype(np.float32)
+        gt[rng.random(want.shape) < 0.1] = np.nan
+        t_gt = torch.from_numpy(gt).cuda()
+        torch.cuda.synchronize()
+        rmse, bpr, n = inst.compare_depth(t_gt.data_ptr(), t_depth.data_ptr(), want.size, 10.0)
+        w_rmse, w_bpr, w_n = compare_depth(gt, want, 10.0)
+        assert n == w_n and abs(bpr - w_bpr) < 1e-12 and abs(rmse - w_rmse) <= 1e-6 * w_rmse
+        # nothing valid in common -> (nan, nan, 0)
+        none = torch.full_like(t_gt, float("nan"))
+        r2 = inst.compare_depth(none.data_ptr(), t_depth.data_ptr(), want.size, 10.0)
+        assert r2[2] == 0 and np.isnan(r2[0]) and np.isnan(r2[1])
+    finally:
+        inst.close()
