@@ -395,7 +395,7 @@ def run_frames(args):
     # the same batches with ONE instance and nothing else on the GPU (after the timed region): the kernels' own launch times,
     # without a second batch competing for VALU issue and HBM
     alone_ms = {}
-    if n_inst > 1 and not args.no_alone:
+    if n_inst > 1 and args.alone:
         for rep in range(2):                             # a first pass to settle, the second one is read
             insts[0].enable_timing(True)
             for k in range(10):
@@ -529,8 +529,10 @@ def main():
                          "tiles mode: frames in flight through the rank pipeline (default 2 x ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-boundary", action="store_true")
-    ap.add_argument("--no-alone", action="store_true",
-                    help="skip the one-batch-in-flight launches behind roofline.alone (so that a kernel trace of this run holds the timed configuration only)")
+    ap.add_argument("--alone", action="store_true",
+                    help="after the timed region also time the batches with ONE instance and nothing else on the GPU -> roofline.alone "
+                         "(off by default: a kernel trace of the default run then holds the timed configuration only, so rocprofv3's "
+                         "per-kernel average and roofline.avg_launch_ms describe the same launches)")
     args = ap.parse_args()
     if args.mode == "tiles":
         from soc_project_stereo_matching_amd.tile_bench import run_tiles
