@@ -126,8 +126,8 @@ bool          sgm_match_device(sgm_instance* s, const uint8_t* d_left, const uin
 bool          sgm_synchronize(sgm_instance* s);
 /* Pipelined host-pointer matches (SGM_Match's H2D / kernels / D2H of SemiGlobalMatching.c:77-78,122 without the
  * blocking wait): sgm_match_async stages the images, queues the upload, the pipeline and the download on the instance's
- * stream and returns; the three buffers stay borrowed until sgm_match_wait (or the next sgm_match_async / sgm_reset with
- * another shape / sgm_destroy on the same instance, which wait implicitly) has handed the result over.  A caller that
+ * stream and returns; the three buffers stay borrowed until sgm_match_wait (or the next sgm_match_async / sgm_initialize /
+ * sgm_reset / sgm_destroy on the same instance, which wait implicitly) has handed the result over.  A caller that
  * round-robins frames over two or three instances overlaps the copies of one with the kernels of the others.
  * sgm_match == sgm_match_async + sgm_match_wait.  Buffers from sgm_host_alloc (page-locked) are used in place: no
  * staging copy on either side; any other host pointer is staged through the instance's own pinned buffers. */
