@@ -228,7 +228,7 @@ def _pipe_worker(rank, world, port, h, w, n_frames, out_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_frames", [(2, 5), (3, 7), (3, 1), (4, 2)])
+@pytest.mark.parametrize("world,n_frames", [(2, 5), (3, 7), (3, 1), (4, 2), (8, 11)])
 def test_frames_in_flight_pipeline_over_gloo(tmp_path, world, n_frames):
     """The systolic schedule: rank r sweeps frame s-r forward and frame s-(N-1-r) backward at step s, one grouped
     exchange per step, the owner of a frame (f mod N) gathers its rows and runs the post pass.  Every frame -- also
