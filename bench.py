@@ -308,7 +308,10 @@ def run_frames(args):
     n_inst = max(1, args.in_flight)
     B = max(1, args.batch)
     insts = [S.SGMInstance(local_rank, batch=B) for _ in range(n_inst)]
+    overlap_post = args.overlap_post if args.overlap_post is not None else int(os.environ.get("SGM_BENCH_OVERLAP_POST", "1"))
     for i in insts:
+        if overlap_post and not i.set_overlap_post(True):
+            raise SystemExit("sgm_set_overlap_post failed")
         if not i.reset(w, h, opt):
             raise SystemExit("sgm_reset failed")
         i.enable_timing(True)
@@ -472,6 +475,7 @@ def run_frames(args):
             "config": {"workload": args.workload, "mode": "frames", "width": w, "height": h, "disparity_range": d, "paths": PATHS,
                        "stages": "census+cost+aggregate8+wta+lrcheck+speckle+median", "frames_per_step": B,
                        "frames_per_gpu": args.steps * B, "batches_in_flight_per_gpu": n_inst,
+                       "post_pass_on_second_stream": bool(overlap_post),
                        "sharding": "independent frames per rank, no collective"},
             "roofline": roofline,
             "roofline_sum_wta": sum_roofline,
@@ -529,6 +533,9 @@ def main():
                          "tiles mode: frames in flight through the rank pipeline (default 2 x ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-boundary", action="store_true")
+    ap.add_argument("--overlap-post", type=int, default=None, choices=[0, 1],
+                    help="sgm_set_overlap_post on the bench's instances: LR check / speckle / median of a batch on a second stream "
+                         "beside the next batch's aggregation (default: SGM_BENCH_OVERLAP_POST or 1)")
     ap.add_argument("--alone", action="store_true",
                     help="after the timed region also time the batches with ONE instance and nothing else on the GPU -> roofline.alone "
                          "(off by default: a kernel trace of the default run then holds the timed configuration only, so rocprofv3's "

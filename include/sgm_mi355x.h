@@ -135,6 +135,13 @@ bool          sgm_match_async(sgm_instance* s, const uint8_t* img_left, const ui
 bool          sgm_match_wait(sgm_instance* s);
 void*         sgm_host_alloc(sgm_instance* s, size_t bytes);   /* page-locked host memory on the instance's device; NULL on failure */
 void          sgm_host_free(sgm_instance* s, void* p);
+/* Throughput option for a stream of matches on ONE instance: with sgm_set_overlap_post(s, 1) the post pass of a match (LR
+ * check, speckle removal, median: latency-bound kernels that occupy a fraction of the GPU) runs on a second stream of the
+ * instance, ordered behind the match's cost sum by an event, while sgm_stream(s) goes on with the census and aggregation of
+ * the next match; the next cost sum waits for the post pass that still reads the shared maps.  Results are unchanged.  What
+ * changes: the disparity map of sgm_match_device is complete after sgm_synchronize (or sgm_match_wait for the host-pointer
+ * form), no longer in stream order of sgm_stream(s).  Off by default; ignored in row-tile mode. */
+bool          sgm_set_overlap_post(sgm_instance* s, int enable);
 /* The HIP stream (hipStream_t as void*) the instance launches on, e.g. to record events. */
 void*         sgm_stream(sgm_instance* s);
 

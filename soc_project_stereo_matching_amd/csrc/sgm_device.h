@@ -20,6 +20,11 @@ int   sgmd_device_is_gfx950(int ordinal);            /* 1 yes, 0 no, <0 error */
 int   sgmd_stream_create(int ordinal, void** stream);
 int   sgmd_stream_destroy(int ordinal, void* stream);
 int   sgmd_stream_sync(int ordinal, void* stream);
+/* events without timing, for ordering one stream behind another */
+int   sgmd_event_create(int ordinal, void** event);
+void  sgmd_event_destroy(int ordinal, void* event);
+int   sgmd_event_record(int ordinal, void* event, void* stream);
+int   sgmd_stream_wait_event(int ordinal, void* stream, void* event);
 int   sgmd_alloc(int ordinal, void** dptr, size_t bytes);
 int   sgmd_free(int ordinal, void* dptr);
 int   sgmd_alloc_pinned(int ordinal, void** hptr, size_t bytes);

@@ -32,6 +32,10 @@ static const int k_dir_dy[8] = {0, 0, 1, -1, 1, -1, -1, 1};
 struct sgm_instance {
     int device;
     void* stream;
+    void* post_stream;           /* sgm_set_overlap_post: LR check, speckle removal and median of a match run here ... */
+    void *ev_sum, *ev_post;      /* ... behind ev_sum (cost sum + WTAs done); ev_post = that post pass done */
+    int overlap_post;
+    bool post_pending;           /* a post pass is (possibly) still running on post_stream */
     void* timer;
     int timing;
     int keep_stages;
@@ -90,6 +94,15 @@ struct sgm_instance {
         fputc('\n', stderr);                       \
         return false;                              \
     } while (0)
+
+/* wait for everything the instance has queued (its stream and, with sgm_set_overlap_post, the post-pass stream) */
+static int sync_streams(sgm_instance* s)
+{
+    int rc = sgmd_stream_sync(s->device, s->stream);
+    if (s->post_stream && sgmd_stream_sync(s->device, s->post_stream) != 0) rc = -1;
+    if (rc == 0) s->post_pending = false;
+    return rc;
+}
 
 /* ------------------------------------------------------------------ path geometry (host) */
 
@@ -200,14 +213,29 @@ void sgm_destroy(sgm_instance* s)
 {
     if (!s) return;
     sgm_match_wait(s);
-    sgmd_stream_sync(s->device, s->stream);
+    sync_streams(s);
     free_device_buffers(s);
     sgmd_timer_destroy(s->device, s->timer);
+    sgmd_event_destroy(s->device, s->ev_sum);
+    sgmd_event_destroy(s->device, s->ev_post);
+    if (s->post_stream) sgmd_stream_destroy(s->device, s->post_stream);
     sgmd_stream_destroy(s->device, s->stream);
     free(s);
 }
 
 void sgm_set_honor_num_paths(sgm_instance* s, int honor) { if (s) s->honor_num_paths = honor; }
+
+bool sgm_set_overlap_post(sgm_instance* s, int enable)
+{
+    if (!s) return false;
+    if (enable && !s->post_stream) {
+        if (sgmd_stream_create(s->device, &s->post_stream) != 0) { s->post_stream = NULL; return false; }
+        if (sgmd_event_create(s->device, &s->ev_sum) != 0 || sgmd_event_create(s->device, &s->ev_post) != 0) return false;
+    }
+    if (!enable && s->overlap_post) sync_streams(s);             /* the next match is ordered on sgm_stream alone again */
+    s->overlap_post = enable ? 1 : 0;
+    return true;
+}
 
 bool sgm_set_census_window(sgm_instance* s, int width, int height)
 {
@@ -241,7 +269,7 @@ void sgm_enable_timing(sgm_instance* s, int enable)
     if (enable && !s->timer && sgmd_timer_create(s->device, &s->timer, TIMING_RING * (T_COUNT + 1)) != 0) return;
     s->timing = enable;
     /* (re-)enabling starts a new statistics window: drop what was recorded before */
-    sgmd_stream_sync(s->device, s->stream);
+    sync_streams(s);
     s->ring_next = s->ring_pending = 0;
     s->n_timed = 0;
     for (int i = 0; i < T_COUNT; ++i) { s->sum_ms[i] = 0; s->min_ms[i] = 1e30; }
@@ -323,7 +351,7 @@ static bool upload_tables(sgm_instance* s)
     ok = ok && sgmd_h2d_async(s->device, s->stream, s->d_row_extras, table, sizeof *table * (size_t)H * cap) == 0 &&
          sgmd_h2d_async(s->device, s->stream, s->d_row_count, count, sizeof(int) * (size_t)H) == 0 &&
          sgmd_h2d_async(s->device, s->stream, s->d_lut, lut, sizeof lut) == 0 &&
-         sgmd_stream_sync(s->device, s->stream) == 0;
+         sync_streams(s) == 0;
     free(table); free(visits); free(count); free(pix);
     if (!ok) FAIL("uploading path tables failed");
     return true;
@@ -338,7 +366,7 @@ static bool ensure_buffers(sgm_instance* s)
     const size_t px = (size_t)s->g.B * s->g.W * s->g.H;          /* all frames of the batch, frame-major */
     int rc = 0;
     if (px > s->cap_px || !s->d_disp) {
-        sgmd_stream_sync(dev, s->stream);
+        sync_streams(s);
         free_device_buffers(s);
         rc |= sgmd_alloc(dev, &s->d_left, px);
         rc |= sgmd_alloc(dev, &s->d_right, px);
@@ -369,7 +397,7 @@ static bool ensure_buffers(sgm_instance* s)
     s->plane_bytes = (size_t)s->plane_rows * s->g.W * s->g.Dp;
     const size_t need = (size_t)s->g.B * 8 * s->plane_bytes;
     if (need > s->cap_planes || !s->d_planes_alloc) {
-        sgmd_stream_sync(dev, s->stream);
+        sync_streams(s);
         sgmd_free(dev, s->d_planes_alloc);
         s->d_planes_alloc = NULL;
         s->cap_planes = 0;
@@ -388,7 +416,7 @@ static int ensure_S(sgm_instance* s)
 {
     const size_t need = (size_t)s->g.B * s->g.W * s->g.H * s->g.Dp * 2;
     if (s->d_S && need <= s->cap_S) return 0;
-    sgmd_stream_sync(s->device, s->stream);
+    sync_streams(s);
     sgmd_free(s->device, s->d_S);
     s->d_S = NULL;
     s->cap_S = 0;
@@ -403,7 +431,7 @@ static int ensure_cost(sgm_instance* s)
 {
     const size_t need = (size_t)s->g.B * s->g.W * s->g.H * s->g.Dp;
     if (s->d_cost && need <= s->cap_cost) return 0;
-    sgmd_stream_sync(s->device, s->stream);
+    sync_streams(s);
     sgmd_free(s->device, s->d_cost);
     s->d_cost = NULL;
     s->cap_cost = 0;
@@ -483,7 +511,7 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
     /* extras: 4 anomalous lines x H steps x Dp bytes */
     const size_t extras_bytes = (size_t)s->g.B * 4 * height * s->g.Dp;
     if (extras_bytes > s->cap_extras || !s->d_extras) {
-        sgmd_stream_sync(s->device, s->stream);
+        sync_streams(s);
         sgmd_free(s->device, s->d_extras);
         s->d_extras = NULL;
         if (sgmd_alloc(s->device, &s->d_extras, extras_bytes) != 0) FAIL("device allocation failed (extras)");
@@ -492,7 +520,7 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
     /* median scratch depends on W and H separately (64-row groups x time slots) */
     const size_t median_bytes = sgmd_median_scratch_bytes(&s->g);
     if (median_bytes > s->cap_median || !s->d_median_scratch) {
-        sgmd_stream_sync(s->device, s->stream);
+        sync_streams(s);
         sgmd_free(s->device, s->d_median_scratch);
         s->d_median_scratch = NULL;
         if (sgmd_alloc(s->device, &s->d_median_scratch, median_bytes) != 0) FAIL("device allocation failed (median scratch)");
@@ -530,16 +558,19 @@ bool sgm_reset(sgm_instance* s, uint16_t width, uint16_t height, const SGMOption
     return sgm_initialize(s, width, height, option);
 }
 
-static void mark(sgm_instance* s, int idx)
+static void mark_on(sgm_instance* s, void* stream, int idx)
 {
-    if (s->timing && s->timer) sgmd_timer_mark(s->device, s->timer, s->stream, s->ring_next * (T_COUNT + 1) + idx);
+    if (s->timing && s->timer) sgmd_timer_mark(s->device, s->timer, stream, s->ring_next * (T_COUNT + 1) + idx);
 }
+static void mark(sgm_instance* s, int idx) { mark_on(s, s->stream, idx); }
 
 /* d_S <- [d_S +] sum of the planes of the last frame, if the fused kernel skipped that store */
 static int materialize_S(sgm_instance* s)
 {
     if (!s->s_pending) return 0;
     if (ensure_S(s) != 0) return -1;
+    /* the scratch map below is the speckle pass's label map: a post pass still running on its own stream comes first */
+    if (s->post_pending && sgmd_stream_wait_event(s->device, s->stream, s->ev_post) != 0) return -1;
     /* the left-view WTA this kernel also produces goes to a dead scratch map (speckle labels) */
     const int rc = sgmd_sum_wta(s->device, s->stream, &s->g, s->paths.ndirs, s->d_planes, s->plane_bytes, s->d_extras,
                                 s->d_row_extras, s->d_row_count, s->row_cap, s->s_pending_accumulate ? 1 : 0, s->d_S, 0, 0.0f,
@@ -588,7 +619,7 @@ static int prepare_costs(sgm_instance* s, const void* d_left, const void* d_righ
     if (!s->census_w) return sgmd_census(s->device, s->stream, &s->g, d_left, d_right, s->d_census_l, s->d_census_r);
     const size_t need = (size_t)s->g.B * s->g.W * s->g.H * 8;
     if (need > s->cap_census64 || !s->d_census64_l) {
-        sgmd_stream_sync(s->device, s->stream);
+        sync_streams(s);
         sgmd_free(s->device, s->d_census64_l);
         sgmd_free(s->device, s->d_census64_r);
         s->d_census64_l = s->d_census64_r = NULL;
@@ -615,16 +646,16 @@ static int launch_aggregation(sgm_instance* s, const sgmd_paths* paths, const vo
 
 /* .c:109 LRCheck on the left map -- or, with the right view as the reference view (extension), the mirrored check on the
  * right map, whose result replaces the left map in d_out */
-static int lr_stage(sgm_instance* s, void* d_out)
+static int lr_stage(sgm_instance* s, void* st, void* d_out)
 {
     const SGMOption* o = &s->opt;
-    if (!s->reference_view) return o->is_check_lr ? sgmd_lrcheck(s->device, s->stream, &s->g, d_out, s->d_disp_r, o->lrcheck_thres) : 0;
+    if (!s->reference_view) return o->is_check_lr ? sgmd_lrcheck(s->device, st, &s->g, d_out, s->d_disp_r, o->lrcheck_thres) : 0;
     /* the rows this instance computes: all rows of all frames of the batch, or (batch 1) its row tile */
     const size_t first = (size_t)s->g.row_begin * s->g.W * sizeof(float);
     const size_t bytes = ((size_t)(s->g.B - 1) * s->g.H + (size_t)(s->g.row_end - s->g.row_begin)) * s->g.W * sizeof(float);
-    int rc = sgmd_lrcheck_right(s->device, s->stream, &s->g, s->d_disp_r, d_out, o->lrcheck_thres, o->is_check_lr ? 1 : 0, s->d_labels);
+    int rc = sgmd_lrcheck_right(s->device, st, &s->g, s->d_disp_r, d_out, o->lrcheck_thres, o->is_check_lr ? 1 : 0, s->d_labels);
     if (rc == 0)                                              /* d_labels: scratch until the speckle pass */
-        rc = sgmd_d2d_async(s->device, s->stream, (char*)d_out + first, (char*)s->d_labels + first, bytes);
+        rc = sgmd_d2d_async(s->device, st, (char*)d_out + first, (char*)s->d_labels + first, bytes);
     return rc;
 }
 
@@ -657,18 +688,33 @@ static bool run_pipeline(sgm_instance* s, const void* d_left, const void* d_righ
             LAUNCH(sgmd_memset_async(dev, st, (char*)s->d_planes_alloc + ((size_t)f * 8 + 4) * s->plane_bytes, 0, 4 * s->plane_bytes));
     LAUNCH(launch_aggregation(s, &s->paths, d_left));                                               /* .c:94 */
     mark(s, 3);
+    /* the cost sum writes d_out and the right-view map, which the previous match's post pass may still be reading */
+    const bool overlap = s->overlap_post && s->post_stream && s->tile_end == 0;
+    if (s->post_pending) LAUNCH(sgmd_stream_wait_event(dev, st, s->ev_post));
     LAUNCH(sum_and_wta(s, d_out, true));                                                            /* .c:94 sum, .c:99, .c:105 */
     if (s->keep_stages) LAUNCH(sgmd_d2d_async(dev, st, s->d_snap_wta, d_out, px_bytes));
     mark(s, 5);
-    LAUNCH(lr_stage(s, d_out));                                                                     /* .c:109 */
-    if (s->keep_stages) LAUNCH(sgmd_d2d_async(dev, st, s->d_snap_lr, d_out, px_bytes));
-    mark(s, 6);
+    /* sgm_set_overlap_post: the post pass (latency-bound kernels that fill a fraction of the GPU) moves to its own stream,
+     * so that this stream can start the next match's census and aggregation beside it */
+    void* st2 = st;
+    if (overlap) {
+        LAUNCH(sgmd_event_record(dev, s->ev_sum, st));
+        LAUNCH(sgmd_stream_wait_event(dev, s->post_stream, s->ev_sum));
+        st2 = s->post_stream;
+    }
+    LAUNCH(lr_stage(s, st2, d_out));                                                                /* .c:109 */
+    if (s->keep_stages) LAUNCH(sgmd_d2d_async(dev, st2, s->d_snap_lr, d_out, px_bytes));
+    mark_on(s, st2, 6);
     if (o->is_remove_speckles)                                                                      /* .c:115 */
-        LAUNCH(sgmd_speckle(dev, st, g, d_out, 1.0f, o->min_speckle_area, s->d_labels, s->d_sizes, s->d_totals));
-    if (s->keep_stages) LAUNCH(sgmd_d2d_async(dev, st, s->d_snap_speckle, d_out, px_bytes));
-    mark(s, 7);
-    LAUNCH(sgmd_median(dev, st, g, d_out, s->d_median_scratch));                                    /* .c:120 */
-    mark(s, 8);
+        LAUNCH(sgmd_speckle(dev, st2, g, d_out, 1.0f, o->min_speckle_area, s->d_labels, s->d_sizes, s->d_totals));
+    if (s->keep_stages) LAUNCH(sgmd_d2d_async(dev, st2, s->d_snap_speckle, d_out, px_bytes));
+    mark_on(s, st2, 7);
+    LAUNCH(sgmd_median(dev, st2, g, d_out, s->d_median_scratch));                                   /* .c:120 */
+    mark_on(s, st2, 8);
+    if (overlap) {
+        LAUNCH(sgmd_event_record(dev, s->ev_post, st2));
+        s->post_pending = true;
+    }
     if (s->timing && s->timer) {
         s->ring_next = (s->ring_next + 1) % TIMING_RING;
         if (s->ring_pending < TIMING_RING) ++s->ring_pending;      /* older sets are overwritten */
@@ -772,7 +818,7 @@ bool sgm_tile_finish(sgm_instance* s, float* d_disp_left)
 {
     if (!s || !s->initialized || !s->tile_left || !d_disp_left) return false;
     int rc = sum_and_wta(s, d_disp_left, false);
-    if (rc == 0) rc = lr_stage(s, d_disp_left);
+    if (rc == 0) rc = lr_stage(s, s->stream, d_disp_left);
     s->tile_left = NULL;
     if (rc != 0) FAIL("a kernel launch failed");
     return true;
@@ -824,7 +870,7 @@ bool sgm_match_device(sgm_instance* s, const uint8_t* d_left, const uint8_t* d_r
 bool sgm_synchronize(sgm_instance* s)
 {
     if (!s) return false;
-    if (sgmd_stream_sync(s->device, s->stream) != 0) return false;
+    if (sync_streams(s) != 0) return false;
     collect_timing(s);
     return true;
 }
@@ -860,9 +906,10 @@ bool sgm_match_async(sgm_instance* s, const uint8_t* img_left, const uint8_t* im
     bool ok = sgmd_h2d_async(s->device, s->stream, s->d_left, src_l, px) == 0 &&
               sgmd_h2d_async(s->device, s->stream, s->d_right, src_r, px) == 0 &&
               run_pipeline(s, s->d_left, s->d_right, s->d_disp) &&
-              sgmd_d2h_async(s->device, s->stream, out_pinned ? (void*)disp_left : s->h_disp, s->d_disp, px * sizeof(float)) == 0;
+              sgmd_d2h_async(s->device, s->post_pending ? s->post_stream : s->stream, out_pinned ? (void*)disp_left : s->h_disp, s->d_disp,
+                             px * sizeof(float)) == 0;
     if (!ok) {
-        sgmd_stream_sync(s->device, s->stream);                  /* queued copies may still read the caller's / staging buffers */
+        sync_streams(s);                  /* queued copies may still read the caller's / staging buffers */
         return false;
     }
     s->async_pending = true;
@@ -952,10 +999,10 @@ size_t sgm_read_stage(sgm_instance* s, int which, void* host_out, size_t capacit
     if (!src) return 0;
     const size_t need = volume ? px * s->g.D * elem : px * elem;
     if (capacity < need) return 0;
-    if (sgmd_stream_sync(s->device, s->stream) != 0) return 0;
+    if (sync_streams(s) != 0) return 0;
     if (!volume) {
         if (sgmd_d2h_async(s->device, s->stream, host_out, src, need) != 0) return 0;
-        if (sgmd_stream_sync(s->device, s->stream) != 0) return 0;
+        if (sync_streams(s) != 0) return 0;
         return need;
     }
     const size_t row_bytes = (size_t)s->g.W * s->g.Dp * elem;
@@ -964,7 +1011,7 @@ size_t sgm_read_stage(sgm_instance* s, int which, void* host_out, size_t capacit
     size_t got = 0;
     if (sgmd_d2h_async(s->device, s->stream, (char*)tmp + (size_t)row_a * row_bytes, src + (size_t)row_a * row_bytes,
                        (size_t)(row_b - row_a) * row_bytes) == 0 &&
-        sgmd_stream_sync(s->device, s->stream) == 0)
+        sync_streams(s) == 0)
         got = compact_volume(s, tmp, elem, host_out);
     free(tmp);
     return got;

@@ -38,6 +38,32 @@ int sgmd_stream_sync(int ord, void* stream)
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return 0;
 }
+int sgmd_event_create(int ord, void** event)
+{
+    HIP_TRY(hipSetDevice(ord));
+    hipEvent_t e;
+    HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    *event = (void*)e;
+    return 0;
+}
+void sgmd_event_destroy(int ord, void* event)
+{
+    if (!event) return;
+    (void)hipSetDevice(ord);
+    (void)hipEventDestroy((hipEvent_t)event);
+}
+int sgmd_event_record(int ord, void* event, void* stream)
+{
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return 0;
+}
+int sgmd_stream_wait_event(int ord, void* stream, void* event)
+{
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return 0;
+}
 int sgmd_alloc(int ord, void** dptr, size_t bytes)
 {
     HIP_TRY(hipSetDevice(ord));

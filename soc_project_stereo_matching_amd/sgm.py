@@ -94,6 +94,8 @@ def load_library() -> C.CDLL:
     L.sgm_create.restype = C.c_void_p
     L.sgm_destroy.argtypes = [C.c_void_p]
     L.sgm_set_honor_num_paths.argtypes = [C.c_void_p, C.c_int]
+    L.sgm_set_overlap_post.argtypes = [C.c_void_p, C.c_int]
+    L.sgm_set_overlap_post.restype = C.c_bool
     L.sgm_set_census_window.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.sgm_set_census_window.restype = C.c_bool
     L.sgm_set_reference_view.argtypes = [C.c_void_p, C.c_int]
@@ -326,6 +328,11 @@ class SGMInstance(_StageReader):
 
     def set_honor_num_paths(self, honor):
         self.lib.sgm_set_honor_num_paths(self.handle, int(honor))
+
+    def set_overlap_post(self, enable: bool = True) -> bool:
+        """The post pass (LR check, speckle, median) of a match on a second stream beside the next match's aggregation;
+        results are complete after synchronize(), not in order of `stream` (include/sgm_mi355x.h)."""
+        return bool(self.lib.sgm_set_overlap_post(self.handle, int(enable)))
 
     def set_census_window(self, width: int, height: int) -> bool:
         """Extension: odd census window of at most 64 pixels (5x5 = reference); next initialize/reset."""

@@ -42,6 +42,10 @@ int sgmd_device_is_gfx950(int o) { (void)o; return 1; }
 int sgmd_stream_create(int o, void** st) { (void)o; *st = malloc(8); return 0; }
 int sgmd_stream_destroy(int o, void* st) { (void)o; free(st); return 0; }
 int sgmd_stream_sync(int o, void* st) { (void)o; (void)st; return note("sync", 0); }
+int sgmd_event_create(int o, void** e) { (void)o; *e = malloc(8); return 0; }
+void sgmd_event_destroy(int o, void* e) { (void)o; free(e); }
+int sgmd_event_record(int o, void* e, void* st) { (void)o; (void)e; (void)st; return note("event_record", 0); }
+int sgmd_stream_wait_event(int o, void* st, void* e) { (void)o; (void)st; (void)e; return note("wait_event", 0); }
 int sgmd_alloc(int o, void** p, size_t n)      /* logged with its size in KiB; nothing the tests do reads the bytes of a volume */
 { (void)o; *p = calloc(1, n > (1u << 20) ? (1u << 20) : (n ? n : 16)); note("alloc", (int)(n >> 10)); return *p ? 0 : 2; }
 int sgmd_free(int o, void* p) { (void)o; free(p); return 0; }

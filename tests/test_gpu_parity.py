@@ -743,3 +743,54 @@ def test_depth_and_scoring_on_device(oracle):
         assert r2[2] == 0 and np.isnan(r2[0]) and np.isnan(r2[1])
     finally:
         inst.close()
+
+
+@pytest.mark.parametrize("batch", [1, 4])
+def test_overlapped_post_pass(oracle, batch):
+    """sgm_set_overlap_post: LR check / speckle / median of a match on the instance's second stream beside the next match's
+    aggregation.  A stream of matches on ONE instance with one output buffer per match, results read after one
+    sgm_synchronize at the end; then the same instance without Reset (Q14 accumulation through the lazy S materialisation,
+    which shares scratch with the post pass), through the host-pointer async entry, and with the option switched off again."""
+    import torch
+    import soc_project_stereo_matching_amd as S
+    from oracle.pyoracle import Oracle, default_option
+    w, h, d, n = 400, 120, 64, 5
+    opt = default_option(d, min_speckle_area=20)
+    inst = S.SGMInstance(0, batch=batch)
+    assert inst.set_overlap_post(True)
+    try:
+        frames = [[oracle.synth_pair(w, h, d, 0x0FE7 + 10 * k + j) for j in range(batch)] for k in range(n)]
+        ins = [(torch.from_numpy(np.stack([p[0] for p in fr])).cuda(), torch.from_numpy(np.stack([p[1] for p in fr])).cuda()) for fr in frames]
+        outs = [torch.empty((batch, h, w), dtype=torch.float32, device="cuda") for _ in range(n)]
+        torch.cuda.synchronize()
+        for k in range(n):
+            assert inst.reset(w, h, opt)
+            assert inst.match_device(ins[k][0].data_ptr(), ins[k][1].data_ptr(), outs[k].data_ptr())
+        assert inst.synchronize()
+        for k in range(n):
+            got = outs[k].cpu().numpy()
+            for j in range(batch):
+                assert_same(got[j], oracle.run(frames[k][j][0], frames[k][j][1], opt)["final"], f"match {k} frame {j}")
+        # Q14 with the post pass still in flight: three matches without Reset on the same output buffer
+        if batch == 1:
+            orc = Oracle()
+            assert orc.reset(w, h, opt) and inst.reset(w, h, opt)
+            for k in range(3):
+                want = orc.match(frames[k][0][0], frames[k][0][1])
+                assert inst.match_device(ins[k][0].data_ptr(), ins[k][1].data_ptr(), outs[0].data_ptr())
+                assert inst.synchronize()
+                assert_same(outs[0].cpu().numpy()[0], want, f"no-reset match {k}")
+        # host pointers, pipelined
+        assert inst.reset(w, h, opt)
+        L = np.stack([p[0] for p in frames[1]]) if batch > 1 else frames[1][0][0]
+        R = np.stack([p[1] for p in frames[1]]) if batch > 1 else frames[1][0][1]
+        O = np.empty(L.shape, np.float32)
+        assert inst.match_async(np.ascontiguousarray(L), np.ascontiguousarray(R), O) and inst.match_wait()
+        for j in range(batch):
+            assert_same(O[j] if batch > 1 else O, oracle.run(frames[1][j][0], frames[1][j][1], opt)["final"], f"async frame {j}")
+        # ... and off again: stream order of sgm_stream alone
+        assert inst.set_overlap_post(False) and inst.reset(w, h, opt)
+        assert inst.match_device(ins[2][0].data_ptr(), ins[2][1].data_ptr(), outs[2].data_ptr()) and inst.synchronize()
+        assert_same(outs[2].cpu().numpy()[0], oracle.run(frames[2][0][0], frames[2][0][1], opt)["final"], "overlap off")
+    finally:
+        inst.close()

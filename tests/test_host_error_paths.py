@@ -263,3 +263,41 @@ def test_extension_options_select_their_stages(host):
         assert names == ["census", "aggregate", "sum_wta_lr", "lrcheck_right", "speckle", "median"]
         assert ("lrcheck_right", int(check_lr)) in log(L)
         L.sgm_destroy(s)
+
+
+def test_overlapped_post_pass_ordering(host):
+    """sgm_set_overlap_post: the post pass goes to a second stream behind an event recorded after the cost sum; the NEXT
+    cost sum (and a lazy S materialisation, which uses the speckle label map as scratch) waits for the event recorded after
+    the post pass; sgm_synchronize waits for both streams."""
+    L = host
+    L.sgm_set_overlap_post.argtypes = [C.c_void_p, C.c_int]
+    L.sgm_set_overlap_post.restype = C.c_bool
+    L.sgm_synchronize.argtypes = [C.c_void_p]
+    L.sgm_synchronize.restype = C.c_bool
+    s, opt = fresh(L)
+    assert L.sgm_set_overlap_post(s, 1)
+    f = Frame()
+    keep = ("sync", "h2d", "d2h", "alloc", "memset")
+    L.stub_clear()
+    assert L.sgm_match_device(s, *f.args())
+    assert [n for n, _ in log(L, drop=keep)] == ["census", "aggregate", "sum_wta_lr", "event_record", "wait_event", "lrcheck", "speckle",
+                                                   "median", "event_record"]
+    L.stub_clear()
+    assert L.sgm_reset(s, 48, 20, C.byref(opt)) and L.sgm_match_device(s, *f.args())
+    names = [n for n, _ in log(L, drop=keep)]
+    assert names[:4] == ["census", "aggregate", "wait_event", "sum_wta_lr"]      # the post pass of the match before still reads the maps
+    L.stub_clear()
+    assert L.sgm_match_device(s, *f.args())                                    # no Reset: S of the previous match is materialised first
+    names = [n for n, _ in log(L, drop=keep)]
+    assert names[:2] == ["sum_wta", "census"]                                  # (allocating S waited for both streams: nothing pending)
+    L.stub_clear()
+    assert L.sgm_match_device(s, *f.args())                                    # again without Reset, S exists now
+    names = [n for n, _ in log(L, drop=keep)]
+    assert names[:3] == ["wait_event", "sum_wta", "census"]                    # the materialisation scribbles on the speckle label map
+    L.stub_clear()
+    assert L.sgm_synchronize(s)
+    assert [L.stub_log_name(i).decode() for i in range(L.stub_log_size())].count("sync") == 2    # both streams
+    L.stub_clear()
+    assert L.sgm_reset(s, 48, 20, C.byref(opt)) and L.sgm_match_device(s, *f.args())
+    assert "wait_event" not in [n for n, _ in log(L, drop=keep)][:3]           # nothing pending after a synchronize
+    L.sgm_destroy(s)
