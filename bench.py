@@ -308,7 +308,7 @@ def run_frames(args):
     n_inst = max(1, args.in_flight)
     B = max(1, args.batch)
     insts = [S.SGMInstance(local_rank, batch=B) for _ in range(n_inst)]
-    overlap_post = args.overlap_post if args.overlap_post is not None else int(os.environ.get("SGM_BENCH_OVERLAP_POST", "1"))
+    overlap_post = args.overlap_post if args.overlap_post is not None else int(os.environ.get("SGM_BENCH_OVERLAP_POST", "0"))
     for i in insts:
         if overlap_post and not i.set_overlap_post(True):
             raise SystemExit("sgm_set_overlap_post failed")
@@ -535,7 +535,8 @@ def main():
     ap.add_argument("--no-host-boundary", action="store_true")
     ap.add_argument("--overlap-post", type=int, default=None, choices=[0, 1],
                     help="sgm_set_overlap_post on the bench's instances: LR check / speckle / median of a batch on a second stream "
-                         "beside the next batch's aggregation (default: SGM_BENCH_OVERLAP_POST or 1)")
+                         "beside the next batch's aggregation (default: SGM_BENCH_OVERLAP_POST or 0: +1..3 %% fps with two batches in "
+                         "flight, +7 %% with one, but the launches then overlap more and the per-launch roofline fractions read lower)")
     ap.add_argument("--alone", action="store_true",
                     help="after the timed region also time the batches with ONE instance and nothing else on the GPU -> roofline.alone "
                          "(off by default: a kernel trace of the default run then holds the timed configuration only, so rocprofv3's "
