@@ -173,6 +173,8 @@ def host_boundary(S, device, w, h, d, opt, pairs, B, digests, seeds, budget_s=6.
         insts = [S.SGMInstance(device, batch=B) for _ in range(n_inst)]
         bufs = []
         for i in insts:
+            if int(os.environ.get("SGM_BENCH_HOST_OVERLAP_POST", "1")):
+                i.set_overlap_post(True)             # a result is handed over by sgm_match_wait anyway: the second stream is free here
             assert i.reset(w, h, opt)
             if kind == "pinned":
                 L, R, O = i.host_array((B, h, w), np.uint8), i.host_array((B, h, w), np.uint8), i.host_array((B, h, w), np.float32)
