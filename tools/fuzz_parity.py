@@ -79,6 +79,8 @@ def main():
         inst.set_reference_view(mode == "rightview")
         keep = bool(rng.random() < 0.5)
         inst.keep_stages(keep)
+        if rng.random() < 0.5:
+            inst.set_overlap_post(True)                   # post pass on the instance's second stream
         try:
             assert inst.reset(w, h, opt), "reset"
             wants = [orc.run(l, r, opt) for l, r in frames]
