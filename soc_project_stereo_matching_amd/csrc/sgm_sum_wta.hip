@@ -120,8 +120,12 @@ static __device__ __forceinline__ void sumlr_prefetch(CellVec<DPL> (&pre)[2][8],
 // every iteration -- which is why columns past the row end re-read the last column instead of being skipped, why
 // the right-view-only iterations after the last column are a loop of their own, and why the anomalous-line
 // visits of the row are staged in LDS up front.
+// TIGHT: the ring holds Dp + COLS columns instead of Dp + 2 COLS and the iteration ends with a second barrier (no wave may
+// write the next iteration's columns while another still reads this one's oldest): for Dp = 256 that is what lets the ring
+// (288 x 258 u16 = 145 KB either way) serve 32 columns = 8 waves per iteration instead of 16 columns = 4 waves -- the kernel
+// is alone on its CU there, so its waves are all the latency hiding it has.
 #define SUMLR_MAX_EXTRA 8
-template <int DPL, bool SLOW, int THREADS>
+template <int DPL, bool SLOW, int THREADS, bool TIGHT = false>
 __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __restrict__ planes, size_t plane_bytes, int ndirs,
                                                         const uint8_t* __restrict__ extras,
                                                         const sgmd_row_extra* __restrict__ row_extras,
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
 #ifdef SGM_SUM_PRIO
     __builtin_amdgcn_s_setprio(SGM_SUM_PRIO);
 #endif
-    constexpr int R = Dp + 2 * COLS;
+    constexpr int R = Dp + (TIGHT ? 1 : 2) * COLS;
     static_assert(R % COLS == 0, "a ring slot must always belong to the same px");
     __shared__ unsigned short ring[R * LD];
     __shared__ unsigned ex_val[SUMLR_MAX_EXTRA * (Dp / 4)];
@@ -247,6 +251,7 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
             float* const out = is_r ? disp_r + xr : disp_l + x;
             out[(size_t)row * W] = wta_finish(st, D, dmin, check_unique, one_minus_ratio);
         }
+        if (TIGHT && do_right) __syncthreads();                          // every diagonal of this iteration has been read
     };
     auto next_slot = [&]() {
         slot += COLS;
@@ -489,14 +494,14 @@ __global__ __launch_bounds__(256) void sgm_lrcheck_right_k(const float* __restri
     out[idx] = d;
 }
 
-template <int DPL, int THREADS>
+template <int DPL, int THREADS, bool TIGHT = false>
 static void launch_sum_wta_lr(dim3 grid, hipStream_t st, const void* planes, size_t plane_bytes, int ndirs, const void* extras,
                               const void* row_extras, const void* row_extra_count, int row_cap, int accumulate, int store_S,
                               int do_right, void* S, void* disp_l, void* disp_r, const sgmd_geom* g, int check_unique,
                               float one_minus_ratio, int seg_len)
 {
 #define SUMLR_CALL(SLOW)                                                                                              \
-    hipLaunchKernelGGL((sgm_sum_wta_lr_k<DPL, SLOW, THREADS>), grid, dim3(THREADS), 0, st, (const uint8_t*)planes, plane_bytes, ndirs, \
+    hipLaunchKernelGGL((sgm_sum_wta_lr_k<DPL, SLOW, THREADS, TIGHT>), grid, dim3(THREADS), 0, st, (const uint8_t*)planes, plane_bytes, ndirs, \
                        (const uint8_t*)extras, (const sgmd_row_extra*)row_extras, (const int*)row_extra_count, row_cap,  \
                        accumulate, store_S, do_right, (uint16_t*)S, (float*)disp_l, (float*)disp_r, g->W, g->H, g->D,    \
                        g->dmin, check_unique, one_minus_ratio, g->row_begin, seg_len)
@@ -565,6 +570,7 @@ int sgmd_sum_wta_lr(int ord, void* stream, const sgmd_geom* g, int ndirs, const 
         while (segs > 1 && g->W / segs < 2 * g->Dp) --segs;
         if (segs < 1) segs = 1;
     }
+    static const int tight = getenv("SGM_SUM_TIGHT") ? atoi(getenv("SGM_SUM_TIGHT")) : 1;   // Dp 192 / 256: see TIGHT above
     const int seg_len = (((g->W + segs - 1) / segs) + 15) / 16 * 16;
     const dim3 grid(g->row_end - g->row_begin, g->B, (g->W + seg_len - 1) / seg_len);
     hipStream_t st = (hipStream_t)stream;
@@ -574,8 +580,14 @@ int sgmd_sum_wta_lr(int ord, void* stream, const sgmd_geom* g, int ndirs, const 
     case 4: launch_sum_wta_lr<4, 256>(SUMLR_ARGS); break;
     case 8: launch_sum_wta_lr<8, 256>(SUMLR_ARGS); break;   // (512 threads = 32 columns per iteration measured the same)
     // larger ranges: the ring takes most of the CU's 160 KB of LDS, one workgroup per CU
-    case 12: launch_sum_wta_lr<12, 512>(SUMLR_ARGS); break;  // Dp 192: ring 256 x 194 u16 =  97 KB, 8 waves
-    case 16: launch_sum_wta_lr<16, 256>(SUMLR_ARGS); break;  // Dp 256: ring 288 x 258 u16 = 145 KB, 4 waves
+    case 12:                                                 // Dp 192: ring 256 x 194 u16 = 97 KB either way
+        if (tight) launch_sum_wta_lr<12, 1024, true>(SUMLR_ARGS);    //   64 columns = 16 waves per iteration
+        else       launch_sum_wta_lr<12, 512>(SUMLR_ARGS);           //   32 columns =  8 waves
+        break;
+    case 16:                                                 // Dp 256: ring 288 x 258 u16 = 145 KB either way
+        if (tight) launch_sum_wta_lr<16, 512, true>(SUMLR_ARGS);     //   32 columns = 8 waves per iteration
+        else       launch_sum_wta_lr<16, 256>(SUMLR_ARGS);           //   16 columns = 4 waves
+        break;
     default:
         fprintf(stderr, "sgm_mi355x: fused sum/WTA needs Dp <= 256 (got %d)\n", g->Dp);
         return -1;
