@@ -13,9 +13,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import soc_project_stereo_matching_amd as S  # noqa: E402
 
-w, h, d, B = 1242, 375, 128, 8
+w, h, d, B = (int(v) for v in (sys.argv[1:5] if len(sys.argv) > 4 else (1242, 375, 128, 8)))
 opt = S.default_option(d)
-for n_inst in (1, 2):
+for n_inst in ((1,) if len(sys.argv) > 4 else (1, 2)):
     insts = [S.SGMInstance(0, batch=B) for _ in range(n_inst)]
     ps = [S.synth_pair(w, h, d, 0x5EED0002 + j) for j in range(B)]
     l = torch.from_numpy(np.stack([p[0] for p in ps])).cuda()
@@ -34,6 +34,13 @@ for n_inst in (1, 2):
             torch.cuda.synchronize()
     torch.cuda.synchronize()
     out = (C.c_ulonglong * 2)()
+    S.load_library().sgmd_debug_clock(0, out)
+    i0 = insts[0]
+    i0.enable_timing(True)
+    for _ in range(3):
+        i0.reset(w, h, opt); i0.match_device(l.data_ptr(), r.data_ptr(), outs[0].data_ptr())
+    i0.synchronize()
+    print("aggregation launch (events, alone):", round(i0.mean_timing()[0]["aggregate"], 3), "ms")
     S.load_library().sgmd_debug_clock(0, out)
     print(f"{n_inst} batch(es) in flight, {k} steps in {time.time() - t0:.1f} s: block 0 of the last aggregation launch lived "
           f"{out[1] / 100.0:.1f} us = {out[0]} shader cycles -> {out[0] / out[1] * 0.1:.3f} GHz", flush=True)
