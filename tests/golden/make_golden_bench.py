@@ -28,7 +28,7 @@ WORKLOADS = {
     "cone_450x375_d64_p8": (450, 375, 64, 0x5EED0001, 16),
     "drivingstereo_1762x800_d192_p8": (1762, 800, 192, 0x5EED0005, 4),
     "middlebury_2880x1988_d256_p8": (2880, 1988, 256, 0x5EED0003, 4),
-    "uhd_3840x2160_d128_p8": (3840, 2160, 128, 0x5EED0006, 4),
+    "uhd_3840x2160_d128_p8": (3840, 2160, 128, 0x5EED0006, 8),
     "uhd_3840x2160_d256_p8": (3840, 2160, 256, 0x5EED0007, 4),
 }
 KEEP = ["disp_l", "disp_r", "after_lr", "after_speckle", "final"]
