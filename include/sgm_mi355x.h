@@ -191,6 +191,21 @@ bool   sgm_disparity_to_depth(sgm_instance* s, const float* d_disparity, size_t 
 bool   sgm_compare_depth(sgm_instance* s, const float* d_ground_truth, const float* d_test, size_t count, float abs_thresh,
                          double* rmse, double* bad_pixel_rate, uint64_t* n_valid);
 
+/* ---- a test-platform frame end to end (the data formats either side of the path) ----
+ * The server hands the board six byte planes per frame -- left B, G, R, right B, G, R, each h rows of w bytes
+ * (HostScript_Server/server.py:105-131; received into frame_buffer.h:16-51 by tcp_perf_client.c:181-189) -- and expects h rows
+ * of w float32 depth in mm back (message type 3, server.py:148-177).  The firmware's grey conversion is
+ * (76 r + 150 g + 29 b) >> 8 (stereo_matching.c:18-25; stb's, behind main.c's image load, uses 77: weight_r selects).
+ *   sgm_gray_from_planes   device buffers: three planes B, G, R of `count` bytes each at d_bgr -> d_gray; on sgm_stream(s).
+ *   sgm_match_planes_async host buffers: queues H2D of the six planes (B frames of six with sgm_set_batch), both grey
+ *                          conversions, the match, disparity -> depth (as sgm_disparity_to_depth) and D2H of the depth map,
+ *                          then returns; sgm_match_wait hands the map over.  Pinned buffers (sgm_host_alloc) are used in
+ *                          place.  The disparity map itself stays readable with sgm_read_stage(s, 8, ...).
+ *   sgm_match_planes       = sgm_match_planes_async + sgm_match_wait. */
+bool   sgm_gray_from_planes(sgm_instance* s, const uint8_t* d_bgr, size_t count, int weight_r, uint8_t* d_gray);
+bool   sgm_match_planes_async(sgm_instance* s, const uint8_t* planes, float fx, float baseline, float doffs, float* depth);
+bool   sgm_match_planes(sgm_instance* s, const uint8_t* planes, float fx, float baseline, float doffs, float* depth);
+
 /* ---- stage read-back (parity tests; copies device -> host, blocking) ----
  * which: 0 census left (u32 [H][W])       1 census right (u32 [H][W])    (u64 words with a wide census window)
  *        2 matching cost (u8 [H][W][D])   3 aggregated cost S (u16 [H][W][D])

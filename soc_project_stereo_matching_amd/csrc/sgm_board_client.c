@@ -93,9 +93,13 @@ int main(int argc, char** argv)
 
     float fx = 0.f, doffs = 0.f, baseline = 0.f;
     int have_calib = 0, frames = 0, cur_w = 0, cur_h = 0, rc = 0;
-    uint8_t *planes = NULL, *gl = NULL, *gr = NULL;
-    float *disp = NULL, *depth = NULL;
+    uint8_t* planes = NULL;
+    float* depth = NULL;
     double t_sgm = 0.0;
+    /* grey conversion, matching and disparity -> depth all run on the GPU (sgm_match_planes); the planes are received
+     * straight into page-locked memory the DMA engines read */
+    sgm_instance* sgm = placeholder ? NULL : sgm_create(0);
+    if (!placeholder && !sgm) { fprintf(stderr, "no usable GPU\n"); close(fd); return 1; }
     const double t_start = now_s();
 
     while (frames < max_frames) {
@@ -105,7 +109,6 @@ int main(int argc, char** argv)
         if (recv_all(fd, hdr, 1)) break;                   /* server closed */
         if (hdr[0] == 0) break;                            /* type 0: no more test data */
         if (recv_all(fd, hdr + 1, 8)) { rc = 1; break; }
-        const int32_t seq = (int32_t)((uint32_t)hdr[1] | ((uint32_t)hdr[2] << 8) | ((uint32_t)hdr[3] << 16) | ((uint32_t)hdr[4] << 24));
         const int w = hdr[5] | (hdr[6] << 8), h = hdr[7] | (hdr[8] << 8);
         if (hdr[0] != 1 && hdr[0] != 2) { fprintf(stderr, "unexpected message type %d\n", hdr[0]); rc = 1; break; }
         if (hdr[0] == 1) {
@@ -118,41 +121,33 @@ int main(int argc, char** argv)
         }
         const size_t px = (size_t)w * h;
         if (w != cur_w || h != cur_h) {
-            free(planes); free(gl); free(gr); free(disp); free(depth);
-            planes = (uint8_t*)malloc(6 * px); gl = (uint8_t*)malloc(px); gr = (uint8_t*)malloc(px);
-            disp = (float*)malloc(px * sizeof(float)); depth = (float*)malloc(px * sizeof(float));
+            if (sgm) { sgm_host_free(sgm, planes); sgm_host_free(sgm, depth); } else { free(planes); free(depth); }
+            planes = (uint8_t*)(sgm ? sgm_host_alloc(sgm, 6 * px) : malloc(6 * px));
+            depth = (float*)(sgm ? sgm_host_alloc(sgm, px * sizeof(float)) : malloc(px * sizeof(float)));
             cur_w = w; cur_h = h;
-            if (!planes || !gl || !gr || !disp || !depth) { rc = 1; break; }
+            if (!planes || !depth) { rc = 1; break; }
         }
-        if (recv_all(fd, planes, 6 * px)) { rc = 1; break; }
-        /* planes: left B, G, R, right B, G, R */
-        for (size_t i = 0; i < px; ++i) {
-            gl[i] = (uint8_t)((76u * planes[2 * px + i] + 150u * planes[px + i] + 29u * planes[i]) >> 8);
-            gr[i] = (uint8_t)((76u * planes[5 * px + i] + 150u * planes[4 * px + i] + 29u * planes[3 * px + i]) >> 8);
-        }
+        if (recv_all(fd, planes, 6 * px)) { rc = 1; break; }       /* left B, G, R, right B, G, R */
         if (placeholder) {
-            for (size_t i = 0; i < px; ++i) depth[i] = (float)gl[i];        /* what the firmware sends today */
+            /* what the firmware sends today: the left grey image as floats (stereo_matching.c:13-33) */
+            for (size_t i = 0; i < px; ++i)
+                depth[i] = (float)(uint8_t)((76u * planes[2 * px + i] + 150u * planes[px + i] + 29u * planes[i]) >> 8);
         } else {
             const double t0 = now_s();
-            if (!SGM_Reset((uint16_t)w, (uint16_t)h, &opt) || !SGM_Match(gl, gr, disp)) { fprintf(stderr, "SGM failed\n"); rc = 1; break; }
-            t_sgm += now_s() - t0;
-            const float fb = (float)((double)fx * (double)baseline);
-            for (size_t i = 0; i < px; ++i) {
-                const float denom = disp[i] + doffs;
-                depth[i] = (isfinite(denom) && denom != 0.0f) ? fb / denom : NAN;
+            if (!sgm_reset(sgm, (uint16_t)w, (uint16_t)h, &opt) || !sgm_match_planes(sgm, planes, fx, baseline, doffs, depth)) {
+                fprintf(stderr, "SGM failed\n"); rc = 1; break;
             }
+            t_sgm += now_s() - t0;
         }
-        uint8_t out[9] = {3, hdr[1], hdr[2], hdr[3], hdr[4], hdr[5], hdr[6], hdr[7], hdr[8]};
+        uint8_t out[9] = {3, hdr[1], hdr[2], hdr[3], hdr[4], hdr[5], hdr[6], hdr[7], hdr[8]};   /* type 3, the frame's seq, w, h */
         if (send_all(fd, out, 9) || send_all(fd, depth, px * sizeof(float))) { rc = 1; break; }
         ++frames;
-        (void)seq;
     }
     const uint8_t bye = 0;
     send_all(fd, &bye, 1);
     close(fd);
     const double dt = now_s() - t_start;
     printf("frames %d in %.3f s (%.2f fps incl. network), SGM %.3f ms/frame\n", frames, dt, frames / (dt > 0 ? dt : 1), frames ? 1e3 * t_sgm / frames : 0.0);
-    if (!placeholder) SGM_Shutdown();
-    free(planes); free(gl); free(gr); free(disp); free(depth);
+    if (sgm) { sgm_host_free(sgm, planes); sgm_host_free(sgm, depth); sgm_destroy(sgm); } else { free(planes); free(depth); }
     return rc;
 }

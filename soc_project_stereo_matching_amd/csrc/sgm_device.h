@@ -145,6 +145,10 @@ int sgmd_depth(int ord, void* stream, const void* disp, size_t n, float fx, floa
 int sgmd_score(int ord, void* stream, const void* ground_truth, const void* test, size_t n, float abs_thresh, double* sum_sq,
                unsigned long long* n_valid, unsigned long long* n_bad);
 
+/* grey = (weight_r r + 150 g + 29 b) >> 8 of three consecutive n-byte planes B, G, R (the test platform's frame
+ * format, server.py:105-131; the firmware's conversion, stereo_matching.c:18-25) */
+int sgmd_gray_planes(int ord, void* stream, const void* bgr, size_t n, int weight_r, void* gray);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,6 +78,8 @@ struct sgm_instance {
     void *d_snap_wta, *d_snap_lr, *d_snap_speckle, *d_totals, *d_median_scratch;
     void *d_census64_l, *d_census64_r;   /* u64 census words of the wide windows (allocated on first use) */
     size_t cap_census64;
+    void *d_bgr, *d_depth, *h_bgr;       /* a test-platform frame's six colour planes, its depth map, pinned staging (first use) */
+    size_t cap_bgr;
     size_t plane_bytes;
     /* pinned staging for the host-pointer entry point */
     void *h_left, *h_right, *h_disp;
@@ -195,7 +197,7 @@ static void free_device_buffers(sgm_instance* s)
     void** all[] = {&s->d_left, &s->d_right, &s->d_census_l, &s->d_census_r_alloc, &s->d_cost, &s->d_planes_alloc, &s->d_extras,
                     &s->d_S, &s->d_disp, &s->d_disp_r, &s->d_labels, &s->d_sizes, &s->d_lut, &s->d_row_extras,
                     &s->d_row_count, &s->d_snap_wta, &s->d_snap_lr, &s->d_snap_speckle, &s->d_totals,
-                    &s->d_median_scratch, &s->d_census64_l, &s->d_census64_r};
+                    &s->d_median_scratch, &s->d_census64_l, &s->d_census64_r, &s->d_bgr, &s->d_depth};
     for (size_t i = 0; i < sizeof all / sizeof all[0]; ++i) {
         sgmd_free(s->device, *all[i]);
         *all[i] = NULL;
@@ -203,8 +205,9 @@ static void free_device_buffers(sgm_instance* s)
     sgmd_free_pinned(s->device, s->h_left);
     sgmd_free_pinned(s->device, s->h_right);
     sgmd_free_pinned(s->device, s->h_disp);
-    s->h_left = s->h_right = s->h_disp = NULL;
-    s->cap_px = s->cap_planes = s->cap_S = s->cap_cost = s->cap_extras = s->cap_median = s->cap_census64 = 0;
+    sgmd_free_pinned(s->device, s->h_bgr);
+    s->h_left = s->h_right = s->h_disp = s->h_bgr = NULL;
+    s->cap_px = s->cap_planes = s->cap_S = s->cap_cost = s->cap_extras = s->cap_median = s->cap_census64 = s->cap_bgr = 0;
     s->cap_H = s->cap_row_cap = 0;
     s->tab_W = s->tab_H = 0;
 }
@@ -937,7 +940,76 @@ bool sgm_disparity_to_depth(sgm_instance* s, const float* d_disparity, size_t co
                             float* d_depth)
 {
     if (!s || !d_disparity || !d_depth) return false;
+    /* the map may be the result of a match whose post pass runs on the second stream (sgm_set_overlap_post) */
+    if (s->post_pending && sgmd_stream_wait_event(s->device, s->stream, s->ev_post) != 0) return false;
     return sgmd_depth(s->device, s->stream, d_disparity, count, fx, baseline, doffs, d_depth) == 0;
+}
+
+/* ------------------------------------------------------------------ a test-platform frame end to end (8f-2) */
+
+bool sgm_gray_from_planes(sgm_instance* s, const uint8_t* d_bgr, size_t count, int weight_r, uint8_t* d_gray)
+{
+    if (!s || !d_bgr || !d_gray) return false;
+    if (weight_r != 76 && weight_r != 77) FAIL("grey weight of red must be 76 (stereo_matching.c:18-25) or 77 (stb_image.h:1746-1749)");
+    return sgmd_gray_planes(s->device, s->stream, d_bgr, count, weight_r, d_gray) == 0;
+}
+
+static int ensure_planes_io(sgm_instance* s)
+{
+    const size_t px = (size_t)s->g.B * s->g.W * s->g.H;
+    if (px <= s->cap_bgr && s->d_bgr) return 0;
+    sync_streams(s);
+    sgmd_free(s->device, s->d_bgr);
+    sgmd_free(s->device, s->d_depth);
+    sgmd_free_pinned(s->device, s->h_bgr);
+    s->d_bgr = s->d_depth = s->h_bgr = NULL;
+    s->cap_bgr = 0;
+    if (sgmd_alloc(s->device, &s->d_bgr, 6 * px) != 0 || sgmd_alloc(s->device, &s->d_depth, px * sizeof(float)) != 0 ||
+        sgmd_alloc_pinned(s->device, &s->h_bgr, 6 * px) != 0)
+        return -1;
+    s->cap_bgr = px;
+    return 0;
+}
+
+/* the stream the instance's last match finishes on (the post-pass stream while sgm_set_overlap_post has work on it) */
+static void* result_stream(sgm_instance* s) { return s->post_pending ? s->post_stream : s->stream; }
+
+bool sgm_match_planes_async(sgm_instance* s, const uint8_t* planes, float fx, float baseline, float doffs, float* depth)
+{
+    if (!s || !s->initialized) return false;
+    if (!planes || !depth) return false;
+    if (s->tile_end != 0) FAIL("the instance is in row-tile mode (sgm_set_rows): use the sgm_tile_* sequence");
+    if (!sgm_match_wait(s)) return false;                        /* the staging buffers are free again */
+    if (ensure_planes_io(s) != 0) FAIL("device allocation failed for the colour planes of %dx%d", s->g.W, s->g.H);
+    const int dev = s->device;
+    const size_t fpx = (size_t)s->g.W * s->g.H, px = (size_t)s->g.B * fpx;
+    const void* src = planes;
+    if (!sgmd_host_is_pinned(dev, planes, 6 * px)) { memcpy(s->h_bgr, planes, 6 * px); src = s->h_bgr; }
+    const bool out_pinned = sgmd_host_is_pinned(dev, depth, px * sizeof(float)) != 0;
+    bool ok = sgmd_h2d_async(dev, s->stream, s->d_bgr, src, 6 * px) == 0;
+    for (int f = 0; ok && f < s->g.B; ++f) {                    /* frame f: left B G R, right B G R (server.py:105-131) */
+        const char* fr = (const char*)s->d_bgr + (size_t)f * 6 * fpx;
+        ok = sgmd_gray_planes(dev, s->stream, fr, fpx, 76, (char*)s->d_left + f * fpx) == 0 &&
+             sgmd_gray_planes(dev, s->stream, fr + 3 * fpx, fpx, 76, (char*)s->d_right + f * fpx) == 0;
+    }
+    ok = ok && run_pipeline(s, s->d_left, s->d_right, s->d_disp);
+    void* st = result_stream(s);
+    ok = ok && sgmd_depth(dev, st, s->d_disp, px, fx, baseline, doffs, s->d_depth) == 0 &&
+         sgmd_d2h_async(dev, st, out_pinned ? (void*)depth : s->h_disp, s->d_depth, px * sizeof(float)) == 0;
+    if (ok && s->post_pending) ok = sgmd_event_record(dev, s->ev_post, st) == 0;   /* the next match's cost sum waits for these too */
+    if (!ok) {
+        sync_streams(s);
+        return false;
+    }
+    s->async_pending = true;
+    s->async_out = out_pinned ? NULL : depth;
+    s->async_bytes = px * sizeof(float);
+    return true;
+}
+
+bool sgm_match_planes(sgm_instance* s, const uint8_t* planes, float fx, float baseline, float doffs, float* depth)
+{
+    return sgm_match_planes_async(s, planes, fx, baseline, doffs, depth) && sgm_match_wait(s);
 }
 
 bool sgm_compare_depth(sgm_instance* s, const float* d_ground_truth, const float* d_test, size_t count, float abs_thresh,
@@ -946,6 +1018,7 @@ bool sgm_compare_depth(sgm_instance* s, const float* d_ground_truth, const float
     if (!s || !d_ground_truth || !d_test) return false;
     double sumsq = 0.0;
     unsigned long long n = 0, bad = 0;
+    if (s->post_pending && sgmd_stream_wait_event(s->device, s->stream, s->ev_post) != 0) return false;
     if (sgmd_score(s->device, s->stream, d_ground_truth, d_test, count, abs_thresh, &sumsq, &n, &bad) != 0) return false;
     if (n_valid) *n_valid = n;
     /* depth_image.py:306-308: (nan, nan, 0) when no pixel is finite in both images */

@@ -690,8 +690,44 @@ __global__ __launch_bounds__(256) void sgm_score_k(const float* __restrict__ gt,
     if (threadIdx.x == 0) { out[blockIdx.x].sumsq = s_sum[0]; out[blockIdx.x].n = s_n[0]; out[blockIdx.x].bad = s_bad[0]; }
 }
 
+// grey = (wr r + 150 g + 29 b) >> 8 of three byte planes B, G, R (stereo_matching.c:18-25: wr = 76; stb_image.h:1746-1749: 77);
+// four pixels per lane when the planes are dword-aligned, else one
+template <bool VEC>
+__global__ __launch_bounds__(256) void sgm_gray_planes_k(const uint8_t* __restrict__ bgr, size_t n, unsigned wr, uint8_t* __restrict__ gray)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (VEC) {
+        if (i * 4 >= n) return;
+        const uint32_t b = ((const uint32_t*)bgr)[i], g = ((const uint32_t*)(bgr + n))[i], r = ((const uint32_t*)(bgr + 2 * n))[i];
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t v = wr * ((r >> (8 * k)) & 255u) + 150u * ((g >> (8 * k)) & 255u) + 29u * ((b >> (8 * k)) & 255u);
+            out |= ((v >> 8) & 255u) << (8 * k);
+        }
+        ((uint32_t*)gray)[i] = out;
+    } else {
+        if (i >= n) return;
+        gray[i] = (uint8_t)((wr * bgr[2 * n + i] + 150u * bgr[n + i] + 29u * bgr[i]) >> 8);
+    }
+}
 
 extern "C" {
+
+int sgmd_gray_planes(int ord, void* stream, const void* bgr, size_t n, int weight_r, void* gray)
+{
+    HIP_TRY(hipSetDevice(ord));
+    if (n == 0) return 0;
+    const bool vec = n % 4 == 0 && ((uintptr_t)bgr | (uintptr_t)gray) % 4 == 0;
+    if (vec)
+        hipLaunchKernelGGL(sgm_gray_planes_k<true>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const uint8_t*)bgr, n, (unsigned)weight_r, (uint8_t*)gray);
+    else
+        hipLaunchKernelGGL(sgm_gray_planes_k<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const uint8_t*)bgr, n, (unsigned)weight_r, (uint8_t*)gray);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 
 int sgmd_depth(int ord, void* stream, const void* disp, size_t n, float fx, float baseline, float doffs, void* depth)
 {

@@ -33,6 +33,7 @@ def compare_depth(ground_truth: np.ndarray, test: np.ndarray, abs_thresh: float 
     return rmse, bpr, n
 
 
-def board_gray(b: np.ndarray, g: np.ndarray, r: np.ndarray) -> np.ndarray:
-    """The firmware's grey conversion (ZedBoard/.../src/stereo_matching.c:18-25): (76 r + 150 g + 29 b) >> 8."""
-    return ((76 * r.astype(np.uint32) + 150 * g.astype(np.uint32) + 29 * b.astype(np.uint32)) >> 8).astype(np.uint8)
+def board_gray(b: np.ndarray, g: np.ndarray, r: np.ndarray, weight_r: int = 76) -> np.ndarray:
+    """The firmware's grey conversion (ZedBoard/.../src/stereo_matching.c:18-25): (76 r + 150 g + 29 b) >> 8;
+    weight_r = 77 gives stb_image's (stb_image.h:1746-1749), the one behind main.c's image load."""
+    return ((weight_r * r.astype(np.uint32) + 150 * g.astype(np.uint32) + 29 * b.astype(np.uint32)) >> 8).astype(np.uint8)

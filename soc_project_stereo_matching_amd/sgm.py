@@ -150,6 +150,11 @@ def load_library() -> C.CDLL:
     L.sgm_compare_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.POINTER(C.c_double),
                                     C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.sgm_compare_depth.restype = C.c_bool
+    L.sgm_gray_from_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    L.sgm_gray_from_planes.restype = C.c_bool
+    for name in ("sgm_match_planes_async", "sgm_match_planes"):
+        getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        getattr(L, name).restype = C.c_bool
     L.sgm_host_walk_line.argtypes = [C.c_int] * 5 + [C.c_void_p]
     L.sgm_host_walk_line.restype = C.c_int
     L.sgm_host_anomalous_line.argtypes = [C.c_int, C.c_int]
@@ -457,6 +462,22 @@ class SGMInstance(_StageReader):
         rmse, bpr, n = C.c_double(), C.c_double(), C.c_uint64()
         ok = self.lib.sgm_compare_depth(self.handle, d_ground_truth, d_test, count, abs_thresh, C.byref(rmse), C.byref(bpr), C.byref(n))
         return (rmse.value, bpr.value, int(n.value)) if ok else None
+
+    # ---- a test-platform frame end to end (include/sgm_mi355x.h) ----
+    def gray_from_planes(self, d_bgr: int, count: int, d_gray: int, weight_r: int = 76) -> bool:
+        """Device pointers: three `count`-byte planes B, G, R -> grey bytes; asynchronous on the instance stream."""
+        return bool(self.lib.sgm_gray_from_planes(self.handle, d_bgr, count, weight_r, d_gray))
+
+    def match_planes(self, planes, fx: float, baseline: float, doffs: float, depth, wait: bool = True) -> bool:
+        """sgm_match_planes(_async): `planes` uint8 [batch *] 6 x H x W (left B, G, R, right B, G, R), `depth` float32 H x W per
+        frame; with wait=False the arrays must stay alive and untouched until match_wait()."""
+        for a in (planes, depth):
+            if not a.flags["C_CONTIGUOUS"]:
+                raise ValueError("match_planes needs C-contiguous arrays")
+        if planes.dtype != np.uint8 or depth.dtype != np.float32:
+            raise TypeError("match_planes: uint8 planes, float32 depth")
+        fn = self.lib.sgm_match_planes if wait else self.lib.sgm_match_planes_async
+        return bool(fn(self.handle, planes.ctypes.data, fx, baseline, doffs, depth.ctypes.data))
 
     @property
     def stream(self) -> int:

@@ -99,5 +99,7 @@ int sgmd_median(int o, void* st, const sgmd_geom* g, void* d, void* s)
 { (void)o; (void)st; (void)g; (void)d; (void)s; return note("median", 0); }
 int sgmd_depth(int o, void* st, const void* d, size_t n, float fx, float b, float doffs, void* out)
 { (void)o; (void)st; (void)d; (void)fx; (void)b; (void)doffs; (void)out; return note("depth", (int)n); }
+int sgmd_gray_planes(int o, void* st, const void* bgr, size_t n, int wr, void* gray)
+{ (void)o; (void)st; (void)bgr; (void)wr; (void)gray; return note("gray", (int)n); }
 int sgmd_score(int o, void* st, const void* g, const void* t, size_t n, float th, double* s, unsigned long long* nv, unsigned long long* nb)
 { (void)o; (void)st; (void)g; (void)t; (void)th; *s = 0; *nv = 0; *nb = 0; return note("score", (int)n); }

@@ -794,3 +794,79 @@ def test_overlapped_post_pass(oracle, batch):
         assert_same(outs[2].cpu().numpy()[0], oracle.run(frames[2][0][0], frames[2][0][1], opt)["final"], "overlap off")
     finally:
         inst.close()
+
+
+def _colour_planes(oracle, w, h, d, seed, rng):
+    """Six planes (left B, G, R, right B, G, R) whose board-grey is close to a synthetic stereo pair, channels perturbed
+    so that the three weights matter."""
+    l, r = oracle.synth_pair(w, h, d, seed)
+    planes = np.empty((6, h, w), np.uint8)
+    for v, g in enumerate((l, r)):
+        for c in range(3):
+            planes[3 * v + c] = np.clip(g.astype(np.int32) + rng.integers(-6, 7, (h, w)), 0, 255)
+    return planes
+
+
+@pytest.mark.parametrize("n", [4096, 1280 * 720, 1001, 3])
+@pytest.mark.parametrize("weight_r", [76, 77])
+def test_gray_from_planes(n, weight_r):
+    """The firmware's grey conversion (stereo_matching.c:18-25; weight 77: stb_image.h:1746-1749) of three byte planes on the
+    device, all 256 values per channel present; dword path (n % 4 == 0) and byte path."""
+    import torch
+    import soc_project_stereo_matching_amd as S
+    from soc_project_stereo_matching_amd.platform import board_gray
+    rng = np.random.default_rng(n + weight_r)
+    bgr = rng.integers(0, 256, (3, n), dtype=np.uint8)
+    bgr[:, :3] = [[255, 0, 255], [255, 0, 0], [255, 255, 0]]                  # the extremes
+    t = torch.from_numpy(bgr).cuda()
+    out = torch.zeros(n + 8, dtype=torch.uint8, device="cuda")               # canary behind the result
+    torch.cuda.synchronize()
+    inst = S.SGMInstance(0)
+    try:
+        assert inst.gray_from_planes(t.data_ptr(), n, out.data_ptr(), weight_r) and inst.synchronize()
+        got = out.cpu().numpy()
+        assert np.array_equal(got[:n], board_gray(bgr[0], bgr[1], bgr[2], weight_r)) and not got[n:].any()
+        assert not inst.gray_from_planes(t.data_ptr(), n, out.data_ptr(), 75)
+    finally:
+        inst.close()
+
+
+@pytest.mark.parametrize("batch,overlap,pinned", [(1, False, False), (1, True, True), (2, True, False), (3, False, True)])
+def test_match_planes_depth(oracle, batch, overlap, pinned):
+    """A test-platform frame end to end on the device: six colour planes in host memory -> grey -> SGM ->
+    depth in mm in host memory.  Expected: the oracle's disparity for the board-grey images pushed through the platform's
+    depth formula (platform.py), bit for bit; the disparity map stays readable as stage 8; a stream of frames on one
+    instance, pageable and pinned buffers, with and without the post pass on the second stream."""
+    import soc_project_stereo_matching_amd as S
+    from oracle.pyoracle import default_option
+    from soc_project_stereo_matching_amd.platform import board_gray, disparity_to_depth
+    w, h, d = 322, 97, 48                                                    # odd row pitch: frames of a batch are not dword-aligned
+    fx, baseline, doffs = 1733.74, 536.62, 0.0
+    opt = S.default_option(d)
+    rng = np.random.default_rng(97)
+    inst = S.SGMInstance(0, batch=batch)
+    try:
+        assert inst.set_overlap_post(overlap)
+        shape_in, shape_out = ((batch, 6, h, w), (batch, h, w)) if batch > 1 else ((6, h, w), (h, w))
+        buf_in = inst.host_array(shape_in, np.uint8) if pinned else np.empty(shape_in, np.uint8)
+        buf_out = inst.host_array(shape_out, np.float32) if pinned else np.empty(shape_out, np.float32)
+        for rep in range(3):
+            planes = np.stack([_colour_planes(oracle, w, h, d, 0x9A00 + 10 * rep + j, rng) for j in range(batch)])
+            buf_in[...] = planes if batch > 1 else planes[0]
+            assert inst.reset(w, h, opt)
+            assert inst.match_planes(buf_in, fx, baseline, doffs, buf_out, wait=(rep != 1))
+            if rep == 1:
+                assert inst.match_wait()
+            got = buf_out.reshape(batch, h, w)
+            for j in range(batch):
+                gl = board_gray(planes[j, 0], planes[j, 1], planes[j, 2])
+                gr = board_gray(planes[j, 3], planes[j, 4], planes[j, 5])
+                disp = oracle.run(gl, gr, default_option(d))["final"]
+                want = disparity_to_depth(disp, fx, baseline, doffs)
+                assert np.array_equal(np.isnan(got[j]), np.isnan(want)), (rep, j)
+                ok = ~np.isnan(want)
+                assert np.array_equal(got[j][ok].view(np.uint32), want[ok].view(np.uint32)), (rep, j)
+                if batch == 1:
+                    assert_same(inst.read_stage("final"), disp, "disparity behind the depth map")
+    finally:
+        inst.close()

@@ -301,3 +301,58 @@ def test_overlapped_post_pass_ordering(host):
     assert L.sgm_reset(s, 48, 20, C.byref(opt)) and L.sgm_match_device(s, *f.args())
     assert "wait_event" not in [n for n, _ in log(L, drop=keep)][:3]           # nothing pending after a synchronize
     L.sgm_destroy(s)
+
+
+def test_platform_frame_entry_stage_order_and_errors(host):
+    """sgm_match_planes: six colour planes -> two grey conversions -> the match -> depth -> one D2H; with the
+    post pass on the second stream the depth conversion follows it there; a refused launch waits for the streams and
+    fails; depth / scoring of an arbitrary device map wait for a pending post pass first."""
+    L = host
+    for f in (L.sgm_match_planes, L.sgm_match_planes_async):
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        f.restype = C.c_bool
+    L.sgm_gray_from_planes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    L.sgm_gray_from_planes.restype = C.c_bool
+    L.sgm_disparity_to_depth.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_void_p]
+    L.sgm_disparity_to_depth.restype = C.c_bool
+    L.sgm_set_overlap_post.argtypes = [C.c_void_p, C.c_int]
+    L.sgm_set_overlap_post.restype = C.c_bool
+    L.sgm_set_rows.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.sgm_set_rows.restype = C.c_bool
+    s, opt = fresh(L)
+    planes = np.zeros((6, 20, 48), np.uint8)
+    depth = np.zeros((20, 48), np.float32)
+    args = (planes.ctypes.data, 1000.0, 100.0, 0.0, depth.ctypes.data)
+    keep = ("sync", "alloc", "memset")
+    assert L.sgm_match_planes_async(s, *args)
+    assert [n for n, _ in log(L, drop=keep)] == ["h2d", "gray", "gray", "census", "aggregate", "sum_wta_lr", "lrcheck", "speckle", "median",
+                                              "depth", "d2h"]
+    assert [a for n, a in log(L, drop=keep) if n in ("gray", "depth")] == [960, 960, 960]
+    assert L.sgm_match_wait(s)
+    # arguments
+    assert not L.sgm_match_planes(s, None, 1000.0, 100.0, 0.0, depth.ctypes.data)
+    assert not L.sgm_match_planes(s, planes.ctypes.data, 1000.0, 100.0, 0.0, None)
+    assert not L.sgm_gray_from_planes(s, planes.ctypes.data, 960, 80, planes.ctypes.data)
+    assert L.sgm_gray_from_planes(s, planes.ctypes.data, 960, 77, planes.ctypes.data)
+    # a refused grey conversion / depth conversion ends the call after waiting for what was queued
+    for stage, nth in (("gray", 1), ("depth", 0)):
+        L.stub_clear()
+        L.stub_fail_at(stage.encode(), nth)
+        assert not L.sgm_match_planes(s, *args)
+        full = [L.stub_log_name(i).decode() for i in range(L.stub_log_size())]
+        assert full[-1] == "sync" and "d2h" not in full
+    # second stream: depth + D2H follow the post pass; a later depth conversion on the main stream waits for its event
+    assert L.sgm_set_overlap_post(s, 1) and L.sgm_reset(s, 48, 20, C.byref(opt))
+    L.stub_clear()
+    assert L.sgm_match_planes_async(s, *args)
+    names = [n for n, _ in log(L, drop=keep)]
+    assert names == ["h2d", "gray", "gray", "census", "aggregate", "sum_wta_lr", "event_record", "wait_event", "lrcheck", "speckle",
+                     "median", "event_record", "depth", "d2h", "event_record"]
+    L.stub_clear()
+    assert L.sgm_disparity_to_depth(s, depth.ctypes.data, 960, 1000.0, 100.0, 0.0, depth.ctypes.data)
+    assert [n for n, _ in log(L, drop=keep)] == ["wait_event", "depth"]
+    assert L.sgm_match_wait(s)
+    # row-tile instances have their own call sequence
+    assert L.sgm_set_rows(s, 0, 10) and L.sgm_reset(s, 48, 20, C.byref(opt))
+    assert not L.sgm_match_planes(s, *args)
+    L.sgm_destroy(s)
