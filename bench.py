@@ -533,6 +533,14 @@ def main():
     ap.add_argument("--in-flight", type=int, default=None,
                     help="frames mode: instances (HIP streams) a rank round-robins batches over (default 2); "
                          "tiles mode: frames in flight through the rank pipeline (default 2 x ranks)")
+    ap.add_argument("--tile-ranks-in-process", type=int, default=0,
+                    help="tiles mode on ONE GPU: this many tile ranks as threads of one process (device copies stand in for xGMI): "
+                         "what the pipeline schedule itself costs against --mode tiles with one rank; not a multi-GPU measurement")
+    ap.add_argument("--tile-lead", type=int, default=int(os.environ.get("SGM_TILE_LEAD", "0")),
+                    help="tiles mode: steps tile_begin of a frame is queued ahead of its first sweep (tiling.TilePipeline lead)")
+    ap.add_argument("--tile-rank-alone", default=None, metavar="r/N",
+                    help="tiles mode: rank r of an N-rank pipeline alone on this GPU with the exchanges skipped: its time per frame "
+                         "(a projection input for N GPUs, results are not produced)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-boundary", action="store_true")
     ap.add_argument("--overlap-post", type=int, default=None, choices=[0, 1],
@@ -545,8 +553,17 @@ def main():
                          "per-kernel average and roofline.avg_launch_ms describe the same launches)")
     args = ap.parse_args()
     if args.mode == "tiles":
-        from soc_project_stereo_matching_amd.tile_bench import run_tiles
+        # a rank of the tile pipeline keeps ~N + 3 HIP streams busy, some with millisecond-long serial kernels (tile_begin's
+        # horizontal lines); on HIP's default of 4 hardware queues short kernels queue up behind those (measured, DESIGN.md
+        # section 7: 1.9 -> 1.45 ms per frame for one rank of eight at 3840x2160).  Read by the runtime when it starts.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+        from soc_project_stereo_matching_amd.tile_bench import run_tiles, run_tiles_in_process
         args.workload = args.workload or "uhd_3840x2160_d128_p8"
+        if args.tile_rank_alone:
+            from soc_project_stereo_matching_amd.tile_bench import run_tile_rank_alone
+            return run_tile_rank_alone(args, args.tile_rank_alone, WORKLOADS)
+        if args.tile_ranks_in_process > 1:
+            return run_tiles_in_process(args, args.tile_ranks_in_process, WORKLOADS, golden_digests)
         return run_tiles(args, init_dist, WORKLOADS, golden_digests)
     args.workload = args.workload or "kitti_1242x375_d128_p8"
     args.in_flight = args.in_flight or 2

@@ -31,9 +31,10 @@ def run_tiles(args, init_dist, WORKLOADS, golden_digests):
         dist.all_reduce(warm)
     w, h, d, seed = WORKLOADS[args.workload]
     opt = S.default_option(d)
-    slots = max(world + 2, args.in_flight or 0)
+    lead = args.tile_lead
+    slots = max(world + 2 + lead, args.in_flight or 0)
     eng = DeviceSlotEngine(local_rank, w, h, opt, tile_rows(h, world)[rank], slots, host_staged=(world > 1 and backend != "nccl"))
-    pipe = TilePipeline(eng, rank, world, h, dist=dist if world > 1 else None)
+    pipe = TilePipeline(eng, rank, world, h, dist=dist if world > 1 else None, lead=lead)
 
     digests = golden_digests(args.workload)
     n_pairs = max(1, min(4, len(digests))) if digests else 2
@@ -84,30 +85,140 @@ def run_tiles(args, init_dist, WORKLOADS, golden_digests):
     eng.close()
 
     if rank == 0:
-        cells = w * h * d
-        dp = -(-d // 16) * 16
-        value = cells * PATHS * args.steps / elapsed / 1e6
-        moved = w * h * dp * 16                                      # planes written once + read once
-        line = {
-            "metric": "Mdisp/s (W*H*D*paths per second), fps beside it",
-            "value": round(value, 1), "unit": "Mdisp/s", "fps": round(args.steps / elapsed, 2),
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u8/u16 integer min-plus (f32 sub-pixel tail)", "data": "synthetic",
-            "config": {"workload": args.workload, "mode": "tiles", "width": w, "height": h, "disparity_range": d, "paths": PATHS,
-                       "stages": "census+cost+aggregate8+wta+lrcheck+speckle+median", "frames": args.steps,
-                       "tile_rows": tile_rows(h, world), "slots_per_rank": slots,
-                       "sharding": f"{world} row tiles per frame; per step one grouped exchange per rank over {backend}: boundary path "
-                                   "costs to both neighbours + finished rows to the frame's owner; speckle+median on the owner"},
-            "roofline": {"bound": "hbm", "kernel": "whole frame (all kernels, all ranks)", "achieved": round(moved * args.steps / elapsed / 1e9, 1),
-                         "peak": HBM_PEAK_GBS * world, "unit": "GB/s", "frac": round(moved * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * world), 4),
-                         "traffic": None, "algorithmic_bytes": "W*H*Dp*16 per frame (eight u8 planes written once and read once)"},
-            "frames_verified": n_ok, "frames_mismatched": n_bad, "frames_without_reference_digest": n_unpinned,
-            "verified_against_golden": (n_bad == 0 and n_ok > 0 and n_unpinned == 0),
-            "verification": f"sha256 of the last {keep_last} frames of the timed region (snapshotted on their owner ranks) vs the "
-                            "reference's own C, tests/golden/bench_frames.json",
-            "cpu_baseline": None,
-        }
-        print(json.dumps(line), flush=True)
+        print(json.dumps(_line(args, w, h, d, world, tile_rows, slots, elapsed, n_ok, n_bad, n_unpinned, keep_last,
+                               f"{world} row tiles per frame; per step one grouped exchange per rank over {backend}: boundary path "
+                               "costs to both neighbours + finished rows to the frame's owner; speckle+median on the owner", world)), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def _line(args, w, h, d, world, tile_rows, slots, elapsed, n_ok, n_bad, n_unpinned, keep_last, sharding, n_gpus):
+    cells = w * h * d
+    dp = -(-d // 16) * 16
+    value = cells * PATHS * args.steps / elapsed / 1e6
+    moved = w * h * dp * 16                                      # planes written once + read once
+    line = {
+        "metric": "Mdisp/s (W*H*D*paths per second), fps beside it",
+        "value": round(value, 1), "unit": "Mdisp/s", "fps": round(args.steps / elapsed, 2),
+        "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u8/u16 integer min-plus (f32 sub-pixel tail)", "data": "synthetic",
+        "config": {"workload": args.workload, "mode": "tiles", "width": w, "height": h, "disparity_range": d, "paths": PATHS,
+                   "stages": "census+cost+aggregate8+wta+lrcheck+speckle+median", "frames": args.steps,
+                   "tile_rows": tile_rows(h, world), "slots_per_rank": slots, "begin_lead_steps": args.tile_lead,
+                   "sharding": sharding},
+        "roofline": {"bound": "hbm", "kernel": "whole frame (all kernels, all ranks)", "achieved": round(moved * args.steps / elapsed / 1e9, 1),
+                     "peak": HBM_PEAK_GBS * n_gpus, "unit": "GB/s", "frac": round(moved * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * n_gpus), 4),
+                     "traffic": None, "algorithmic_bytes": "W*H*Dp*16 per frame (eight u8 planes written once and read once)"},
+        "frames_verified": n_ok, "frames_mismatched": n_bad, "frames_without_reference_digest": n_unpinned,
+        "verified_against_golden": (n_bad == 0 and n_ok > 0 and n_unpinned == 0),
+        "verification": f"sha256 of the last {keep_last} frames of the timed region (snapshotted on their owner ranks) vs the "
+                        "reference's own C, tests/golden/bench_frames.json",
+        "cpu_baseline": None,
+    }
+    return line
+
+
+def run_tiles_in_process(args, ranks, WORKLOADS, golden_digests):
+    """The same pipeline with `ranks` tile ranks as THREADS of this process on ONE GPU (tiling.InProcessGroup: device copies
+    stand in for the xGMI transfers).  Not a multi-GPU measurement -- it shows what the schedule itself costs: `ranks` tiles per
+    frame, every hand-over and the row gather in place, against the one-rank pipeline on the same GPU."""
+    import threading
+    import torch
+    import soc_project_stereo_matching_amd as S
+    from .tiling import DeviceSlotEngine, InProcessGroup, TilePipeline, tile_rows
+
+    w, h, d, seed = WORKLOADS[args.workload]
+    opt = S.default_option(d)
+    lead = args.tile_lead
+    slots = max(ranks + 2 + lead, args.in_flight or 0)
+    group = InProcessGroup(ranks)
+    digests = golden_digests(args.workload)
+    n_pairs = max(1, min(4, len(digests))) if digests else 2
+    pairs = [S.synth_pair(w, h, d, seed + k) for k in range(n_pairs)]
+    frames = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in pairs]
+    torch.cuda.synchronize()
+    get = lambda f: frames[f % n_pairs]                              # noqa: E731
+    keep_last = 2 * ranks
+    snaps, errors, times = {}, [], [0.0, 0.0]
+    bar = threading.Barrier(ranks)
+
+    def rank_main(r):
+        try:
+            torch.cuda.set_device(0)
+            eng = DeviceSlotEngine(0, w, h, opt, tile_rows(h, ranks)[r], slots, host_staged=False)
+            pipe = TilePipeline(eng, r, ranks, h, dist=group.view(r), lead=lead)
+
+            def on_result(f, tensor, event):
+                if f >= args.steps - keep_last:
+                    with torch.cuda.stream(eng.stream[f % slots]):
+                        snaps[f] = tensor.clone()
+
+            pipe.run(max(args.warmup, 1), get)
+            torch.cuda.synchronize()
+            bar.wait()
+            if r == 0:
+                times[0] = time.perf_counter()
+            pipe.run(args.steps, get, on_result, throttle=slots)
+            torch.cuda.synchronize()
+            bar.wait()
+            if r == 0:
+                times[1] = time.perf_counter()
+            eng.close()
+        except Exception as exc:                                      # noqa: BLE001
+            errors.append((r, repr(exc)))
+            bar.abort()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(ranks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errors:
+        raise RuntimeError(f"in-process tile ranks failed: {errors}")
+    elapsed = times[1] - times[0]
+    n_ok = n_bad = n_unpinned = 0
+    for f, t in sorted(snaps.items()):
+        sd = seed + f % n_pairs
+        if sd not in digests:
+            n_unpinned += 1
+        elif hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest() == digests[sd]:
+            n_ok += 1
+        else:
+            n_bad += 1
+    line = _line(args, w, h, d, ranks, tile_rows, slots, elapsed, n_ok, n_bad, n_unpinned, keep_last,
+                 f"{ranks} row tiles per frame driven by {ranks} threads of one process on ONE GPU (device copies stand in for xGMI): "
+                 "the schedule's own cost, not a multi-GPU measurement", 1)
+    line["config"]["mode"] = f"tiles, {ranks} in-process ranks on one GPU"
+    print(json.dumps(line), flush=True)
+
+
+def run_tile_rank_alone(args, spec, WORKLOADS):
+    """`spec` = "r/N": rank r of an N-rank pipeline alone on this GPU, exchanges replaced by nothing (tiling.NullGroup).  Prints the
+    rank's time per frame: 1 / max over the ranks of it is the rate N GPUs could reach with the exchanges fully hidden -- a
+    projection from measured single-GPU work, NOT a multi-GPU measurement (results are not verified: there are none)."""
+    import torch
+    import soc_project_stereo_matching_amd as S
+    from .tiling import DeviceSlotEngine, NullGroup, TilePipeline, tile_rows
+    r, n = (int(v) for v in spec.split("/"))
+    w, h, d, seed = WORKLOADS[args.workload]
+    opt = S.default_option(d)
+    lead = args.tile_lead
+    slots = max(n + 2 + lead, args.in_flight or 0)
+    eng = DeviceSlotEngine(0, w, h, opt, tile_rows(h, n)[r], slots, host_staged=False)
+    pipe = TilePipeline(eng, r, n, h, dist=NullGroup(), lead=lead)
+    pairs = [S.synth_pair(w, h, d, seed + k) for k in range(2)]
+    frames = [(torch.from_numpy(l).cuda(), torch.from_numpy(rt).cuda()) for l, rt in pairs]
+    torch.cuda.synchronize()
+    get = lambda f: frames[f % 2]                                     # noqa: E731
+    pipe.run(max(args.warmup, 1), get)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pipe.run(args.steps, get, None, throttle=slots)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    eng.close()
+    print(json.dumps({"tile_rank_alone": spec, "lead": lead, "slots": slots, "workload": args.workload, "rows": tile_rows(h, n)[r], "frames": args.steps,
+                      "ms_per_frame": round(el / args.steps * 1e3, 4), "fps_if_this_rank_were_the_slowest": round(args.steps / el, 2),
+                      "note": "one rank's share of an N-rank pipeline alone on one GPU, exchanges skipped: a projection input, not a result"}),
+          flush=True)

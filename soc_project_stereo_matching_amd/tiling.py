@@ -366,26 +366,33 @@ class TilePipeline:
          `tensor` ([H][W]) is the slot's map: valid after `event` (None = already complete) and until the slot is reused,
          slots - world - 1 steps later -- copy or consume it before."""
 
-    def __init__(self, engine: SlotEngine, rank: int, world: int, height: int, dist=None):
-        if engine.slots < world + 2:
-            raise ValueError(f"{world} ranks need at least {world + 2} slots per rank, got {engine.slots}")
-        self.e, self.rank, self.world, self.h, self.dist = engine, rank, world, height, dist
+    def __init__(self, engine: SlotEngine, rank: int, world: int, height: int, dist=None, lead: int = 0):
+        if lead < 0:
+            raise ValueError("lead must be >= 0")
+        if engine.slots < world + 2 + lead:
+            raise ValueError(f"{world} ranks with a lead of {lead} need at least {world + 2 + lead} slots per rank, got {engine.slots}")
+        self.e, self.rank, self.world, self.h, self.dist, self.lead = engine, rank, world, height, dist, lead
         self.rows = tile_rows(height, world)
 
     def run(self, n_frames: int, get_frame, on_result=None, throttle: int = 0):
-        e, r, N, F = self.e, self.rank, self.world, n_frames
+        """`lead`: tile_begin of a frame is queued `lead` steps before its first sweep can start.  tile_begin is the longest serial
+        chain of a tile (its horizontal lines: W - 1 dependent steps, whatever the number of ranks) and uses a fraction of the
+        GPU; queued in the step of the first sweep (lead 0) it is on the critical path of rank 0 and rank N-1 -- every step then
+        lasts tile_begin + sweep -- with a lead it runs beside the sweeps of the frames before."""
+        e, r, N, F, K = self.e, self.rank, self.world, n_frames, self.lead
         R = e.slots
         slot = lambda f: f % R                                       # noqa: E731
         valid = lambda f: 0 <= f < F                                 # noqa: E731
         lag = max(r, N - 1 - r)
         step_done = []
-        for s in range(F + N + 1):
-            if throttle and s >= throttle and step_done[s - throttle] is not None:
-                step_done[s - throttle].synchronize()                # bound the host's run-ahead
+        for step in range(F + N + 1 + K):
+            if throttle and step >= throttle and step_done[step - throttle] is not None:
+                step_done[step - throttle].synchronize()             # bound the host's run-ahead
             touched = set()
-            if valid(s):
-                l, rt = get_frame(s)
-                e.begin(slot(s), l, rt)
+            if valid(step):
+                l, rt = get_frame(step)
+                e.begin(slot(step), l, rt)
+            s = step - K                                             # the schedule of the header comment, K steps behind the begins
             f, g = s - r, s - (N - 1 - r)
             for forward, fr in ((True, f), (False, g)):
                 if not valid(fr):
@@ -425,5 +432,67 @@ class TilePipeline:
                     else:
                         ops += [("recv", m[self.rows[k][0]:self.rows[k][1]], k) for k in range(N) if k != r]
                 e.exchange(self.dist, ops, sorted(touched))
-            step_done.append(e.done(slot(s)) if throttle else None)
+            step_done.append(e.done(slot(step)) if throttle else None)
         e.drain()
+
+
+class InProcessGroup:
+    """N ranks as N threads of ONE process on one GPU: what a TilePipeline rehearsal passes as `dist` when there is no process
+    group.  A send is a device copy into a staging tensor (standing in for the xGMI transfer) queued to the peer with a HIP
+    event; the matching receive waits for the event on the receiver's communication stream and copies into its buffer.  Sends
+    of a group are queued before its receives are waited for, like a grouped RCCL exchange: no order of the ranks deadlocks.
+    `view(rank)` is the object a rank hands to TilePipeline / DeviceSlotEngine.exchange."""
+
+    class _Op:
+        def __init__(self, kind, tensor, peer):
+            self.kind, self.tensor, self.peer = kind, tensor, peer
+
+    class _View:
+        isend, irecv = "send", "recv"
+
+        def __init__(self, group, rank):
+            self.group, self.rank = group, rank
+
+        def P2POp(self, kind, tensor, peer):
+            return InProcessGroup._Op(kind, tensor, peer)
+
+        def batch_isend_irecv(self, ops):
+            import torch
+            st = torch.cuda.current_stream() if any(op.tensor.is_cuda for op in ops) else None   # host tensors: the CPU tests
+            for op in ops:
+                if op.kind == "send":
+                    stage, ev = op.tensor.clone(), None
+                    if st is not None:
+                        ev = torch.cuda.Event()
+                        ev.record(st)
+                    self.group.q[(self.rank, op.peer)].put((stage, ev))
+            for op in ops:
+                if op.kind == "recv":
+                    stage, ev = self.group.q[(op.peer, self.rank)].get(timeout=self.group.timeout)
+                    if ev is not None:
+                        st.wait_event(ev)
+                    op.tensor.copy_(stage)
+                    if ev is not None:
+                        stage.record_stream(st)          # allocated on the sender's stream, last read on this one
+            return []
+
+    def __init__(self, world: int, timeout: float = 120.0):
+        import queue
+        self.world, self.timeout = world, timeout
+        self.q = {(a, b): queue.Queue() for a in range(world) for b in range(world) if a != b}
+
+    def view(self, rank: int):
+        return InProcessGroup._View(self, rank)
+
+
+class NullGroup:
+    """A `dist` whose exchanges move nothing: ONE rank of an N-rank pipeline runs alone on its GPU, with whatever its hand-over
+    buffers hold.  The results are meaningless; the launches, their sizes and their order are exactly the rank's share of the
+    work, so the time per step is what that rank's GPU would need if the exchanges cost nothing (bench.py --tile-rank-alone)."""
+    isend, irecv = "send", "recv"
+
+    def P2POp(self, kind, tensor, peer):
+        return None
+
+    def batch_isend_irecv(self, ops):
+        return []

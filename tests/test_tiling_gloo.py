@@ -200,7 +200,7 @@ class ToySlotEngine:
         pass
 
 
-def _pipe_worker(rank, world, port, h, w, n_frames, out_path):
+def _pipe_worker(rank, world, port, h, w, n_frames, out_path, lead=0):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -211,8 +211,8 @@ def _pipe_worker(rank, world, port, h, w, n_frames, out_path):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     l, r = _images(h, w)
-    eng = ToySlotEngine(h, w, tile_rows(h, world)[rank], world + 2)
-    pipe = TilePipeline(eng, rank, world, h, dist=dist)
+    eng = ToySlotEngine(h, w, tile_rows(h, world)[rank], world + 2 + lead)
+    pipe = TilePipeline(eng, rank, world, h, dist=dist, lead=lead)
     got = {}
     import time
     for rep in range(2):                                            # the pipeline object is reusable
@@ -223,13 +223,13 @@ def _pipe_worker(rank, world, port, h, w, n_frames, out_path):
         assert f % world == rank                                    # only a frame's owner runs its post pass
         np.save(f"{out_path}.rep{rep}.f{f}.npy", t.numpy())
     assert sum(1 for e in eng.log if e[0] == "post") == 2 * len(range(rank, n_frames, world))
-    assert eng.exchanges <= 2 * (n_frames + world + 1)              # one grouped exchange per step
+    assert eng.exchanges <= 2 * (n_frames + world + 1 + lead)       # one grouped exchange per step
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n_frames", [(2, 5), (3, 7), (3, 1), (4, 2), (8, 11)])
-def test_frames_in_flight_pipeline_over_gloo(tmp_path, world, n_frames):
+@pytest.mark.parametrize("world,n_frames,lead", [(2, 5, 0), (3, 7, 0), (3, 1, 0), (4, 2, 0), (8, 11, 0), (3, 7, 2), (2, 1, 3), (4, 9, 1)])
+def test_frames_in_flight_pipeline_over_gloo(tmp_path, world, n_frames, lead):
     """The systolic schedule: rank r sweeps frame s-r forward and frame s-(N-1-r) backward at step s, one grouped
     exchange per step, the owner of a frame (f mod N) gathers its rows and runs the post pass.  Every frame -- also
     when there are fewer frames than ranks, and across two runs of the same pipeline -- equals the one-tile result."""
@@ -238,7 +238,7 @@ def test_frames_in_flight_pipeline_over_gloo(tmp_path, world, n_frames):
     from soc_project_stereo_matching_amd.tiling import match_tiled
     h, w = 23, 17
     out = str(tmp_path / "p")
-    mp.spawn(_pipe_worker, args=(world, _free_port(), h, w, n_frames, out), nprocs=world, join=True)
+    mp.spawn(_pipe_worker, args=(world, _free_port(), h, w, n_frames, out, lead), nprocs=world, join=True)
     l, r = _images(h, w)
     for f in range(n_frames):
         want = match_tiled(ToyEngine(h, w, (0, h)), 0, 1, torch.from_numpy(l) + f, torch.from_numpy(r), h).numpy()
@@ -257,11 +257,50 @@ def test_pipeline_single_rank_and_slot_guard():
     l, r = _images(h, w)
     with pytest.raises(ValueError):
         TilePipeline(ToySlotEngine(h, w, (0, h), 2), 0, 1, h)       # needs world + 2 slots
+    with pytest.raises(ValueError):
+        TilePipeline(ToySlotEngine(h, w, (0, h), 4), 0, 1, h, lead=2)   # ... + lead
     eng = ToySlotEngine(h, w, (0, h), 3)
     got = {}
     TilePipeline(eng, 0, 1, h).run(4, lambda f: (torch.from_numpy(l) + f, torch.from_numpy(r)),
                                    lambda f, t, ev: got.__setitem__(f, t.clone()))
     assert sorted(got) == [0, 1, 2, 3]
+    got2 = {}
+    TilePipeline(ToySlotEngine(h, w, (0, h), 5), 0, 1, h, lead=2).run(4, lambda f: (torch.from_numpy(l) + f, torch.from_numpy(r)),
+                                                                      lambda f, t, ev: got2.__setitem__(f, t.clone()))
+    assert sorted(got2) == [0, 1, 2, 3] and all(torch.equal(got[f], got2[f]) for f in got)
     for f in range(4):
         want = match_tiled(ToyEngine(h, w, (0, h)), 0, 1, torch.from_numpy(l) + f, torch.from_numpy(r), h)
         assert torch.equal(got[f], want)
+
+
+@pytest.mark.parametrize("world,n_frames,lead", [(2, 5, 0), (3, 7, 2), (5, 3, 1)])
+def test_pipeline_ranks_as_threads_of_one_process(world, n_frames, lead):
+    """tiling.InProcessGroup: the ranks as threads of one process (what bench.py --tile-ranks-in-process runs on one GPU), the
+    exchange as queued copies.  Same results as the one-tile run, whatever order the threads reach their exchanges in."""
+    import threading
+    import torch
+    from soc_project_stereo_matching_amd.tiling import InProcessGroup, TilePipeline, match_tiled, tile_rows
+    h, w = 23, 17
+    l, r = _images(h, w)
+    group = InProcessGroup(world, timeout=60)
+    got, errors = {}, []
+
+    def rank_main(rank):
+        try:
+            eng = ToySlotEngine(h, w, tile_rows(h, world)[rank], world + 2 + lead)
+            TilePipeline(eng, rank, world, h, dist=group.view(rank), lead=lead).run(
+                n_frames, lambda f: (torch.from_numpy(l) + f, torch.from_numpy(r)), lambda f, t, ev: got.__setitem__(f, (rank, t.clone())))
+        except Exception as exc:                                    # noqa: BLE001
+            errors.append((rank, repr(exc)))
+
+    th = [threading.Thread(target=rank_main, args=(k,)) for k in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+    assert not errors, errors
+    assert sorted(got) == list(range(n_frames))
+    for f in range(n_frames):
+        want = match_tiled(ToyEngine(h, w, (0, h)), 0, 1, torch.from_numpy(l) + f, torch.from_numpy(r), h)
+        assert got[f][0] == f % world and torch.equal(got[f][1], want), f
+    assert all(q.empty() for q in group.q.values())                 # every send met its receive
