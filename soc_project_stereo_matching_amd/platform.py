@@ -13,7 +13,10 @@ def disparity_to_depth(disp: np.ndarray, fx: float, baseline: float, doffs: floa
     """depth[mm] = fx * baseline / (disparity + doffs) (depth_image.py:138-165); invalid (+inf / nan) disparities
     and a zero denominator give NaN, as in the platform's client simulator (client.py:40-45).  float32."""
     disp = np.asarray(disp, np.float32)
-    denom = disp + np.float32(doffs)
+    # the board knows the calibration as the float32 values of the 80-byte block (stereo_calibration.py:177-195, client.py:31-37);
+    # their product is formed in double and rounded once, like client.py:44's python-float product against a float32 array
+    fx, baseline, doffs = np.float32(fx), np.float32(baseline), np.float32(doffs)
+    denom = disp + doffs
     depth = np.full(disp.shape, np.nan, np.float32)
     ok = np.isfinite(denom) & (denom != 0)
     depth[ok] = np.float32(float(fx) * float(baseline)) / denom[ok]

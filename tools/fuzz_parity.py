@@ -38,6 +38,39 @@ def tiles_case(orc, rng, w, h, d, opt, frame, seed, kw):
             e.close()
 
 
+def planes_case(orc, rng, w, h, d, opt, oopt, seed, kw):
+    """a batch of test-platform frames (six colour planes each) through sgm_match_planes against oracle -> depth formula"""
+    from soc_project_stereo_matching_amd.platform import board_gray, disparity_to_depth
+    B = int(rng.integers(1, 4))
+    fx, baseline, doffs = float(rng.choice([1733.74, 3979.9, 100.0])), float(rng.choice([536.62, 193.0])), float(rng.choice([0.0, 124.3, -3.0]))
+    planes = np.empty((B, 6, h, w), np.uint8)
+    for j in range(B):
+        l, r = orc.synth_pair(w, h, d, seed + j)
+        for v, g in enumerate((l, r)):
+            for c in range(3):
+                planes[j, 3 * v + c] = np.clip(g.astype(np.int32) + rng.integers(-9, 10, (h, w)), 0, 255)
+    inst = S.SGMInstance(0, batch=B)
+    try:
+        if rng.random() < 0.5:
+            inst.set_overlap_post(True)
+        pinned = rng.random() < 0.5
+        src = inst.host_array(planes.shape, np.uint8) if pinned else np.empty_like(planes)
+        src[...] = planes
+        out = inst.host_array((B, h, w), np.float32) if pinned else np.empty((B, h, w), np.float32)
+        assert inst.reset(w, h, opt), "reset"
+        assert inst.match_planes(src if B > 1 else src[0], fx, baseline, doffs, out if B > 1 else out[0]), "match_planes"
+        for j in range(B):
+            disp = orc.run(board_gray(planes[j, 0], planes[j, 1], planes[j, 2]), board_gray(planes[j, 3], planes[j, 4], planes[j, 5]), oopt)["final"]
+            want = disparity_to_depth(disp, fx, baseline, doffs)
+            ok = ~np.isnan(want)
+            if not (np.array_equal(np.isnan(out[j]), np.isnan(want)) and np.array_equal(out[j][ok].view(np.uint32), want[ok].view(np.uint32))):
+                print(f"MISMATCH planes {w}x{h} d={d} B={B} frame {j} seed={seed} calib=({fx},{baseline},{doffs}) opts={kw}", flush=True)
+                return 1
+        return 0
+    finally:
+        inst.close()
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
@@ -57,7 +90,8 @@ def main():
                   uniqueness_ratio=float(rng.choice([0.99, 0.95, 0.8])), lrcheck_thres=float(rng.choice([1.0, 0.0, 2.5])))
         opt = default_option(dmin + d, dmin, **kw)
         seed = int(rng.integers(1, 2**31))
-        mode = str(rng.choice(["plain", "plain", "batch", "separate", "window", "rightview", "tiles"]))
+        modes = os.environ.get("FUZZ_MODES", "plain,plain,batch,separate,window,rightview,tiles,planes").split(",")
+        mode = str(rng.choice(modes))
         if mode == "tiles" and h < 4:
             mode = "plain"
         B = int(rng.integers(2, 5)) if mode == "batch" else 1
@@ -69,6 +103,10 @@ def main():
             win = [(7, 7), (9, 7), (3, 5), (7, 9), (1, 1), (63, 1)][int(rng.integers(0, 6))]
         orc.set_census_window(*win)
         orc.set_reference_view(mode == "rightview")
+        if mode == "planes":
+            n += 1
+            bad += planes_case(orc, rng, w, h, d, S.default_option(dmin + d, dmin, **kw), opt, seed, kw)
+            continue
         if mode == "tiles":
             n_bad = tiles_case(orc, rng, w, h, d, opt, frames[0], seed, kw)
             n += 1
