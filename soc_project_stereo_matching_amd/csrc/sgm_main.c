@@ -7,6 +7,9 @@
  *   sgm_main LEFT RIGHT OUT.png|OUT.pgm [--min-disparity N] [--max-disparity N] [--p1 N] [--p2 N]
  *            [--no-lr] [--lr-thres F] [--no-unique] [--unique-ratio F] [--no-speckle] [--speckle-area N]
  *            [--raw OUT.f32] [--repeat N] [--device N]
+ *            [--paths 4|8] [--census WxH] [--right-reference]      extensions of the boundary: 4-path
+ *            aggregation (the reference stores num_paths and ignores it), census windows other than 5x5, the right image
+ *            as reference view; the defaults are the reference's behaviour
  *   sgm_main --convert IN OUT.png        (image I/O only, no GPU: used by the CPU tests)
  */
 #define _POSIX_C_SOURCE 200809L
@@ -60,7 +63,7 @@ int main(int argc, char** argv)
     opt.p1 = 10;
     opt.p2_init = 150;
     const char* raw_path = NULL;
-    int repeat = 1, device = -1;
+    int repeat = 1, device = -1, census_w = 0, census_h = 0, right_ref = 0;
     for (int i = 4; i < argc; ++i) {
         const char* a = argv[i];
         const char* v = (i + 1 < argc) ? argv[i + 1] : NULL;
@@ -77,6 +80,12 @@ int main(int argc, char** argv)
         else if (v && !strcmp(a, "--raw")) { raw_path = v; ++i; }
         else if (v && !strcmp(a, "--repeat")) { repeat = atoi(v); ++i; }
         else if (v && !strcmp(a, "--device")) { device = atoi(v); ++i; }
+        else if (v && !strcmp(a, "--paths")) { opt.num_paths = (uint8_t)atoi(v); SGM_SetHonorNumPaths(1); ++i; }
+        else if (v && !strcmp(a, "--census")) {
+            if (sscanf(v, "%dx%d", &census_w, &census_h) != 2) { fprintf(stderr, "--census wants WxH, e.g. 7x7\n"); return 2; }
+            ++i;
+        }
+        else if (!strcmp(a, "--right-reference")) right_ref = 1;
         else { fprintf(stderr, "unknown option %s\n", a); return 2; }
     }
 
@@ -89,6 +98,8 @@ int main(int argc, char** argv)
     printf("w = %d, h = %d, d = [%d,%d]\n", w1, h1, opt.min_disparity, opt.max_disparity);
 
     if (device >= 0) SGM_SetDevice(device);
+    if (census_w && !SGM_SetCensusWindow(census_w, census_h)) { printf("unsupported census window %dx%d\n", census_w, census_h); return -2; }
+    if (right_ref) SGM_SetReferenceView(1);
     if (!SGM_Initialize((uint16_t)w1, (uint16_t)h1, &opt)) { printf("SGM initialization failed\n"); return -2; }
     float* disp = (float*)malloc(sizeof(float) * (size_t)w1 * h1);
     double best = 1e30;

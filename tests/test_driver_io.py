@@ -56,3 +56,10 @@ def test_rejects_what_it_cannot_read(exe, tmp_path):
     assert subprocess.call([exe, "--convert", im16, str(tmp_path / "o.png")], stderr=subprocess.DEVNULL) != 0
     assert subprocess.call([exe, "--convert", str(tmp_path / "missing.png"), str(tmp_path / "o.png")],
                            stderr=subprocess.DEVNULL) != 0
+
+
+def test_extension_flags_are_parsed_before_anything_else(exe, tmp_path):
+    """--census wants WxH; unknown options are refused (no GPU is touched for either)."""
+    for bad in (["--census", "7"], ["--census"], ["--right-ref"]):
+        out = subprocess.run([exe, "a.png", "b.png", str(tmp_path / "o.png")] + bad, capture_output=True, text=True)
+        assert out.returncode == 2, (bad, out.stderr)

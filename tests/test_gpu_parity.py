@@ -870,3 +870,39 @@ def test_match_planes_depth(oracle, batch, overlap, pinned):
                     assert_same(inst.read_stage("final"), disp, "disparity behind the depth map")
     finally:
         inst.close()
+
+
+@pytest.mark.parametrize("flags,setup", [
+    (["--paths", "4"], dict(honor=True, num_paths=4)),
+    (["--census", "7x7"], dict(window=(7, 7))),
+    (["--right-reference"], dict(right=True)),
+    (["--census", "9x7", "--right-reference", "--min-disparity", "3", "--max-disparity", "40"], dict(window=(9, 7), right=True, dmin=3, dmax=40)),
+])
+def test_c_driver_extension_flags(tmp_path, oracle, flags, setup):
+    """sgm_main's --paths / --census / --right-reference (SURVEY.md 8f-4 as command-line options): the raw disparities equal
+    the oracle's with the same extension switched on (the reference has none of them: parity unpinned by the reference)."""
+    import os
+    import subprocess
+    from PIL import Image
+    from conftest import ROOT
+    from oracle.pyoracle import default_option
+    exe = os.path.join(ROOT, "soc_project_stereo_matching_amd", "sgm_main")
+    w, h = 203, 77
+    dmin, dmax = setup.get("dmin", 0), setup.get("dmax", 64)
+    left, right = oracle.synth_pair(w, h, dmax - dmin, 0xC11)
+    Image.fromarray(left).save(str(tmp_path / "l.png"))
+    Image.fromarray(right).save(str(tmp_path / "r.pgm"))
+    out_raw = str(tmp_path / "d.f32")
+    base = ["--max-disparity", "64"] if "--max-disparity" not in flags else []
+    subprocess.check_call([exe, str(tmp_path / "l.png"), str(tmp_path / "r.pgm"), str(tmp_path / "d.png"), "--raw", out_raw] + base + flags)
+    opt = default_option(dmax, dmin, num_paths=setup.get("num_paths", 8))
+    try:
+        oracle.set_honor_num_paths(setup.get("honor", False))
+        oracle.set_census_window(*setup.get("window", (5, 5)))
+        oracle.set_reference_view(setup.get("right", False))
+        want = oracle.run(left, right, opt)["final"]
+    finally:
+        oracle.set_honor_num_paths(False)
+        oracle.set_census_window(5, 5)
+        oracle.set_reference_view(False)
+    assert_same(np.fromfile(out_raw, np.float32).reshape(h, w), want, f"driver {flags}")
