@@ -528,7 +528,9 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--mode", default="frames", choices=["frames", "tiles"])
-    ap.add_argument("--batch", type=int, default=8, help="frames per step (one launch per stage covers them all)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="frames per step, one launch per stage covers them all (frames mode: default 8; tiles mode: default 1 = "
+                         "one frame cut into the ranks' tiles per step, N = the same tile of N frames per launch)")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--in-flight", type=int, default=None,
                     help="frames mode: instances (HIP streams) a rank round-robins batches over (default 2); "
@@ -566,6 +568,7 @@ def main():
             return run_tiles_in_process(args, args.tile_ranks_in_process, WORKLOADS, golden_digests)
         return run_tiles(args, init_dist, WORKLOADS, golden_digests)
     args.workload = args.workload or "kitti_1242x375_d128_p8"
+    args.batch = args.batch or 8
     args.in_flight = args.in_flight or 2
     run_frames(args)
 

@@ -168,7 +168,9 @@ void          sgm_select_frame(sgm_instance* s, int frame);
  *
  * d_left / d_right are the whole images (replicated); buf holds sgm_tile_boundary_bytes(s) bytes of device
  * memory: the path costs of one image row for the 3 directions of a sweep (1 with four paths).  The two
- * sweeps are independent of each other.  The result is bit-identical to sgm_match on one GPU. */
+ * sweeps are independent of each other.  The result is bit-identical to sgm_match on one GPU.
+ * With sgm_set_batch(s, B) every call covers the same rows of B frames ([B][H][W] images and maps; the hand-over buffer holds
+ * B such rows, frame-major): one launch per stage for the B tiles -- a tile of a single frame leaves most of a GPU idle. */
 bool   sgm_set_rows(sgm_instance* s, int row_begin, int row_end);
 bool   sgm_tile_begin(sgm_instance* s, const uint8_t* d_left, const uint8_t* d_right);
 size_t sgm_tile_boundary_bytes(const sgm_instance* s);

@@ -33,6 +33,10 @@ int   sgmd_host_is_pinned(int ordinal, const void* hptr, size_t bytes);   /* 1: 
 int   sgmd_h2d_async(int ordinal, void* stream, void* dst, const void* src, size_t bytes);
 int   sgmd_d2h_async(int ordinal, void* stream, void* dst, const void* src, size_t bytes);
 int   sgmd_d2d_async(int ordinal, void* stream, void* dst, const void* src, size_t bytes);
+/* One image row of up to 8 direction planes of every frame of the batch <-> a packed buffer [frame][k][row_bytes] (the row-tile
+ * hand-over): plane d = dirs[k] of frame f starts at planes + (f * 8 + d) * plane_bytes; to_buf != 0 gathers, else scatters. */
+int   sgmd_plane_rows_copy(int ordinal, void* stream, void* planes, size_t plane_bytes, size_t row_offset, size_t row_bytes,
+                           const int* dirs, int ndirs, int frames, void* buf, int to_buf);
 int   sgmd_memset_async(int ordinal, void* stream, void* dst, int value, size_t bytes);
 
 /* ---- per-stage timing with HIP events on the stream ---- */

@@ -490,7 +490,6 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
     if (s->tile_end != 0) {
         if (s->tile_begin < 0 || s->tile_begin >= s->tile_end || s->tile_end > height)
             FAIL("row tile [%d,%d) does not fit a frame of %d rows", s->tile_begin, s->tile_end, height);
-        if (s->batch != 1) FAIL("row tiles need batch == 1");
         s->g.row_begin = s->tile_begin; s->g.row_end = s->tile_end;
     }
     s->tile_left = NULL;
@@ -653,12 +652,14 @@ static int lr_stage(sgm_instance* s, void* st, void* d_out)
 {
     const SGMOption* o = &s->opt;
     if (!s->reference_view) return o->is_check_lr ? sgmd_lrcheck(s->device, st, &s->g, d_out, s->d_disp_r, o->lrcheck_thres) : 0;
-    /* the rows this instance computes: all rows of all frames of the batch, or (batch 1) its row tile */
-    const size_t first = (size_t)s->g.row_begin * s->g.W * sizeof(float);
-    const size_t bytes = ((size_t)(s->g.B - 1) * s->g.H + (size_t)(s->g.row_end - s->g.row_begin)) * s->g.W * sizeof(float);
+    /* the rows this instance computes: all rows of all frames of the batch, or its row tile of each of them */
     int rc = sgmd_lrcheck_right(s->device, st, &s->g, s->d_disp_r, d_out, o->lrcheck_thres, o->is_check_lr ? 1 : 0, s->d_labels);
-    if (rc == 0)                                              /* d_labels: scratch until the speckle pass */
-        rc = sgmd_d2d_async(s->device, st, (char*)d_out + first, (char*)s->d_labels + first, bytes);
+    const size_t frame = (size_t)s->g.W * s->g.H * sizeof(float), first = (size_t)s->g.row_begin * s->g.W * sizeof(float);
+    const size_t rows = (size_t)(s->g.row_end - s->g.row_begin) * s->g.W * sizeof(float);
+    if (rows == frame)                                        /* d_labels: scratch until the speckle pass */
+        return rc ? rc : sgmd_d2d_async(s->device, st, d_out, s->d_labels, frame * s->g.B);
+    for (int f = 0; rc == 0 && f < s->g.B; ++f)
+        rc = sgmd_d2d_async(s->device, st, (char*)d_out + f * frame + first, (char*)s->d_labels + f * frame + first, rows);
     return rc;
 }
 
@@ -768,8 +769,9 @@ bool sgm_tile_begin(sgm_instance* s, const uint8_t* d_left, const uint8_t* d_rig
     if (!s || !s->initialized || !d_left || !d_right) return false;
     int rc = s->s_is_zero ? 0 : materialize_S(s);
     if (rc == 0) rc = prepare_costs(s, d_left, d_right);
-    if (rc == 0 && s->need_plane_memset && s->paths.ndirs > 4)
-        rc = sgmd_memset_async(s->device, s->stream, (char*)s->d_planes_alloc + 4 * s->plane_bytes, 0, 4 * s->plane_bytes);
+    if (s->need_plane_memset && s->paths.ndirs > 4)
+        for (int f = 0; rc == 0 && f < s->g.B; ++f)
+            rc = sgmd_memset_async(s->device, s->stream, (char*)s->d_planes_alloc + ((size_t)f * 8 + 4) * s->plane_bytes, 0, 4 * s->plane_bytes);
     if (rc != 0) FAIL("a kernel launch failed");
     s->tile_left = d_left;
     int hmask = 0;
@@ -781,7 +783,7 @@ bool sgm_tile_begin(sgm_instance* s, const uint8_t* d_left, const uint8_t* d_rig
 size_t sgm_tile_boundary_bytes(const sgm_instance* s)
 {
     if (!s || !s->initialized) return 0;
-    return (size_t)(s->paths.ndirs > 4 ? 3 : 1) * s->g.W * s->g.Dp;
+    return (size_t)s->g.B * (s->paths.ndirs > 4 ? 3 : 1) * s->g.W * s->g.Dp;     /* [frame of the batch][direction of the sweep][W][Dp] */
 }
 
 /* rows of the planes a sweep hands over: `inside` = the tile's last row in walking order, else the row just past
@@ -794,15 +796,12 @@ static bool boundary_copy(sgm_instance* s, int forward, void* d_buf, bool do_exp
     if (row < 0 || row >= s->g.H) return false;               /* the tile touches the frame edge: nothing to import */
     const size_t row_bytes = (size_t)s->g.W * s->g.Dp;
     const int mask = sweep_mask(s, forward);
-    int n = 0, rc = 0;
-    for (int d = 0; d < s->paths.ndirs && rc == 0; ++d) {
-        if (!((mask >> d) & 1)) continue;
-        char* cell = (char*)s->d_planes + (size_t)d * s->plane_bytes + (size_t)row * row_bytes;
-        char* slot = (char*)d_buf + (size_t)n++ * row_bytes;
-        rc = do_export ? sgmd_d2d_async(s->device, s->stream, slot, cell, row_bytes)
-                       : sgmd_d2d_async(s->device, s->stream, cell, slot, row_bytes);
-    }
-    return rc == 0;
+    int dirs[8], n = 0;
+    for (int d = 0; d < s->paths.ndirs; ++d)
+        if ((mask >> d) & 1) dirs[n++] = d;
+    /* one launch for all frames and directions: [frame][direction of the sweep][W][Dp] in the buffer */
+    return sgmd_plane_rows_copy(s->device, s->stream, s->d_planes, s->plane_bytes, (size_t)row * row_bytes, row_bytes, dirs, n, s->g.B,
+                                d_buf, do_export ? 1 : 0) == 0;
 }
 
 bool sgm_tile_export_boundary(sgm_instance* s, int forward, void* d_buf) { return boundary_copy(s, forward, d_buf, true); }

@@ -116,6 +116,33 @@ int sgmd_d2h_async(int ord, void* stream, void* dst, const void* src, size_t byt
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
     return 0;
 }
+struct PlaneRows { int dirs[8]; };
+__global__ __launch_bounds__(256) void sgm_plane_rows_copy_k(uint8_t* planes, size_t plane_bytes, size_t row_offset, unsigned row_vecs,
+                                                             PlaneRows pr, int ndirs, uint8_t* buf, int to_buf)
+{
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= row_vecs) return;
+    const int k = blockIdx.y, f = blockIdx.z;
+    uint4* cell = reinterpret_cast<uint4*>(planes + ((size_t)f * 8 + (size_t)pr.dirs[k]) * plane_bytes + row_offset) + i;
+    uint4* slot = reinterpret_cast<uint4*>(buf + ((size_t)f * ndirs + k) * (size_t)row_vecs * 16) + i;
+    if (to_buf) *slot = *cell;
+    else *cell = *slot;
+}
+
+int sgmd_plane_rows_copy(int ord, void* stream, void* planes, size_t plane_bytes, size_t row_offset, size_t row_bytes, const int* dirs,
+                         int ndirs, int frames, void* buf, int to_buf)
+{
+    HIP_TRY(hipSetDevice(ord));
+    if (ndirs <= 0 || ndirs > 8 || frames <= 0 || row_bytes % 16 != 0 || plane_bytes % 16 != 0) return -1;   /* Dp is a multiple of 16 */
+    PlaneRows pr;
+    for (int k = 0; k < 8; ++k) pr.dirs[k] = k < ndirs ? dirs[k] : 0;
+    const unsigned vecs = (unsigned)(row_bytes / 16);
+    hipLaunchKernelGGL(sgm_plane_rows_copy_k, dim3((vecs + 255) / 256, ndirs, frames), dim3(256), 0, (hipStream_t)stream, (uint8_t*)planes,
+                       plane_bytes, row_offset, vecs, pr, ndirs, (uint8_t*)buf, to_buf);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int sgmd_d2d_async(int ord, void* stream, void* dst, const void* src, size_t bytes)
 {
     HIP_TRY(hipSetDevice(ord));

@@ -18,6 +18,38 @@ PATHS = 8
 HBM_PEAK_GBS = 8000.0
 
 
+def _inputs(S, torch, w, h, d, seed, digests, B):
+    """Device-resident synthetic input of the pipeline: a few distinct batches of B pairs ([B][H][W], or [H][W] for B = 1) whose
+    seeds have reference digests; returns (get_frame(f), seeds_of(f))."""
+    n_known = len(digests) if digests else 0
+    n_batches = max(1, min(4, n_known // B)) if n_known >= B else 2
+    batches, seeds = [], []
+    for k in range(n_batches):
+        ps = [S.synth_pair(w, h, d, seed + k * B + j) for j in range(B)]
+        seeds.append([seed + k * B + j for j in range(B)])
+        if B == 1:
+            batches.append((torch.from_numpy(ps[0][0]).cuda(), torch.from_numpy(ps[0][1]).cuda()))
+        else:
+            batches.append((torch.from_numpy(np.stack([p[0] for p in ps])).cuda(), torch.from_numpy(np.stack([p[1] for p in ps])).cuda()))
+    torch.cuda.synchronize()
+    return (lambda f: batches[f % n_batches]), (lambda f: seeds[f % n_batches])
+
+
+def _verify(snaps, seeds_of, digests, B):
+    digests = digests or {}
+    n_ok = n_bad = n_unpinned = 0
+    for f, t in sorted(snaps.items()):
+        maps = t.cpu().numpy().reshape((B,) + tuple(t.shape[-2:]))
+        for j, sd in enumerate(seeds_of(f)):
+            if sd not in digests:
+                n_unpinned += 1
+            elif hashlib.sha256(maps[j].tobytes()).hexdigest() == digests[sd]:
+                n_ok += 1
+            else:
+                n_bad += 1
+    return n_ok, n_bad, n_unpinned
+
+
 def run_tiles(args, init_dist, WORKLOADS, golden_digests):
     import torch
     import torch.distributed as dist
@@ -31,17 +63,13 @@ def run_tiles(args, init_dist, WORKLOADS, golden_digests):
         dist.all_reduce(warm)
     w, h, d, seed = WORKLOADS[args.workload]
     opt = S.default_option(d)
-    lead = args.tile_lead
+    lead, B = args.tile_lead, max(1, args.batch or 1)
     slots = max(world + 2 + lead, args.in_flight or 0)
-    eng = DeviceSlotEngine(local_rank, w, h, opt, tile_rows(h, world)[rank], slots, host_staged=(world > 1 and backend != "nccl"))
+    eng = DeviceSlotEngine(local_rank, w, h, opt, tile_rows(h, world)[rank], slots, host_staged=(world > 1 and backend != "nccl"), batch=B)
     pipe = TilePipeline(eng, rank, world, h, dist=dist if world > 1 else None, lead=lead)
 
     digests = golden_digests(args.workload)
-    n_pairs = max(1, min(4, len(digests))) if digests else 2
-    pairs = [S.synth_pair(w, h, d, seed + k) for k in range(n_pairs)]
-    frames = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in pairs]
-    torch.cuda.synchronize()
-    get = lambda f: frames[f % n_pairs]                              # noqa: E731
+    get, seeds_of = _inputs(S, torch, w, h, d, seed, digests, B)
 
     def barrier():
         if world > 1:
@@ -65,15 +93,7 @@ def run_tiles(args, init_dist, WORKLOADS, golden_digests):
     barrier()
     elapsed = time.perf_counter() - t0
 
-    n_ok = n_bad = n_unpinned = 0
-    for f, t in sorted(snaps.items()):
-        sd = seed + f % n_pairs
-        if sd not in digests:
-            n_unpinned += 1
-        elif hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest() == digests[sd]:
-            n_ok += 1
-        else:
-            n_bad += 1
+    n_ok, n_bad, n_unpinned = _verify(snaps, seeds_of, digests, B)
     if world > 1:
         dev = "cuda" if backend == "nccl" else "cpu"
         t = torch.tensor([elapsed, float(n_ok), float(n_bad), float(n_unpinned)], dtype=torch.float64, device=dev)
@@ -85,34 +105,35 @@ def run_tiles(args, init_dist, WORKLOADS, golden_digests):
     eng.close()
 
     if rank == 0:
-        print(json.dumps(_line(args, w, h, d, world, tile_rows, slots, elapsed, n_ok, n_bad, n_unpinned, keep_last,
+        print(json.dumps(_line(args, B, w, h, d, world, tile_rows, slots, elapsed, n_ok, n_bad, n_unpinned, keep_last,
                                f"{world} row tiles per frame; per step one grouped exchange per rank over {backend}: boundary path "
                                "costs to both neighbours + finished rows to the frame's owner; speckle+median on the owner", world)), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def _line(args, w, h, d, world, tile_rows, slots, elapsed, n_ok, n_bad, n_unpinned, keep_last, sharding, n_gpus):
+def _line(args, B, w, h, d, world, tile_rows, slots, elapsed, n_ok, n_bad, n_unpinned, keep_last, sharding, n_gpus):
+    frames = args.steps * B                                          # a step = one slot = B frames
     cells = w * h * d
     dp = -(-d // 16) * 16
-    value = cells * PATHS * args.steps / elapsed / 1e6
+    value = cells * PATHS * frames / elapsed / 1e6
     moved = w * h * dp * 16                                      # planes written once + read once
     line = {
         "metric": "Mdisp/s (W*H*D*paths per second), fps beside it",
-        "value": round(value, 1), "unit": "Mdisp/s", "fps": round(args.steps / elapsed, 2),
+        "value": round(value, 1), "unit": "Mdisp/s", "fps": round(frames / elapsed, 2),
         "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "u8/u16 integer min-plus (f32 sub-pixel tail)", "data": "synthetic",
         "config": {"workload": args.workload, "mode": "tiles", "width": w, "height": h, "disparity_range": d, "paths": PATHS,
-                   "stages": "census+cost+aggregate8+wta+lrcheck+speckle+median", "frames": args.steps,
+                   "stages": "census+cost+aggregate8+wta+lrcheck+speckle+median", "frames": frames, "frames_per_step": B,
                    "tile_rows": tile_rows(h, world), "slots_per_rank": slots, "begin_lead_steps": args.tile_lead,
                    "sharding": sharding},
-        "roofline": {"bound": "hbm", "kernel": "whole frame (all kernels, all ranks)", "achieved": round(moved * args.steps / elapsed / 1e9, 1),
-                     "peak": HBM_PEAK_GBS * n_gpus, "unit": "GB/s", "frac": round(moved * args.steps / elapsed / 1e9 / (HBM_PEAK_GBS * n_gpus), 4),
+        "roofline": {"bound": "hbm", "kernel": "whole frame (all kernels, all ranks)", "achieved": round(moved * frames / elapsed / 1e9, 1),
+                     "peak": HBM_PEAK_GBS * n_gpus, "unit": "GB/s", "frac": round(moved * frames / elapsed / 1e9 / (HBM_PEAK_GBS * n_gpus), 4),
                      "traffic": None, "algorithmic_bytes": "W*H*Dp*16 per frame (eight u8 planes written once and read once)"},
         "frames_verified": n_ok, "frames_mismatched": n_bad, "frames_without_reference_digest": n_unpinned,
         "verified_against_golden": (n_bad == 0 and n_ok > 0 and n_unpinned == 0),
-        "verification": f"sha256 of the last {keep_last} frames of the timed region (snapshotted on their owner ranks) vs the "
+        "verification": f"sha256 of the frames of the last {keep_last} steps of the timed region (snapshotted on their owner ranks) vs the "
                         "reference's own C, tests/golden/bench_frames.json",
         "cpu_baseline": None,
     }
@@ -130,15 +151,11 @@ def run_tiles_in_process(args, ranks, WORKLOADS, golden_digests):
 
     w, h, d, seed = WORKLOADS[args.workload]
     opt = S.default_option(d)
-    lead = args.tile_lead
+    lead, B = args.tile_lead, max(1, args.batch or 1)
     slots = max(ranks + 2 + lead, args.in_flight or 0)
     group = InProcessGroup(ranks)
     digests = golden_digests(args.workload)
-    n_pairs = max(1, min(4, len(digests))) if digests else 2
-    pairs = [S.synth_pair(w, h, d, seed + k) for k in range(n_pairs)]
-    frames = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in pairs]
-    torch.cuda.synchronize()
-    get = lambda f: frames[f % n_pairs]                              # noqa: E731
+    get, seeds_of = _inputs(S, torch, w, h, d, seed, digests, B)
     keep_last = 2 * ranks
     snaps, errors, times = {}, [], [0.0, 0.0]
     bar = threading.Barrier(ranks)
@@ -146,7 +163,7 @@ def run_tiles_in_process(args, ranks, WORKLOADS, golden_digests):
     def rank_main(r):
         try:
             torch.cuda.set_device(0)
-            eng = DeviceSlotEngine(0, w, h, opt, tile_rows(h, ranks)[r], slots, host_staged=False)
+            eng = DeviceSlotEngine(0, w, h, opt, tile_rows(h, ranks)[r], slots, host_staged=False, batch=B)
             pipe = TilePipeline(eng, r, ranks, h, dist=group.view(r), lead=lead)
 
             def on_result(f, tensor, event):
@@ -177,16 +194,8 @@ def run_tiles_in_process(args, ranks, WORKLOADS, golden_digests):
     if errors:
         raise RuntimeError(f"in-process tile ranks failed: {errors}")
     elapsed = times[1] - times[0]
-    n_ok = n_bad = n_unpinned = 0
-    for f, t in sorted(snaps.items()):
-        sd = seed + f % n_pairs
-        if sd not in digests:
-            n_unpinned += 1
-        elif hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest() == digests[sd]:
-            n_ok += 1
-        else:
-            n_bad += 1
-    line = _line(args, w, h, d, ranks, tile_rows, slots, elapsed, n_ok, n_bad, n_unpinned, keep_last,
+    n_ok, n_bad, n_unpinned = _verify(snaps, seeds_of, digests, B)
+    line = _line(args, B, w, h, d, ranks, tile_rows, slots, elapsed, n_ok, n_bad, n_unpinned, keep_last,
                  f"{ranks} row tiles per frame driven by {ranks} threads of one process on ONE GPU (device copies stand in for xGMI): "
                  "the schedule's own cost, not a multi-GPU measurement", 1)
     line["config"]["mode"] = f"tiles, {ranks} in-process ranks on one GPU"
@@ -203,14 +212,11 @@ def run_tile_rank_alone(args, spec, WORKLOADS):
     r, n = (int(v) for v in spec.split("/"))
     w, h, d, seed = WORKLOADS[args.workload]
     opt = S.default_option(d)
-    lead = args.tile_lead
+    lead, B = args.tile_lead, max(1, args.batch or 1)
     slots = max(n + 2 + lead, args.in_flight or 0)
-    eng = DeviceSlotEngine(0, w, h, opt, tile_rows(h, n)[r], slots, host_staged=False)
+    eng = DeviceSlotEngine(0, w, h, opt, tile_rows(h, n)[r], slots, host_staged=False, batch=B)
     pipe = TilePipeline(eng, r, n, h, dist=NullGroup(), lead=lead)
-    pairs = [S.synth_pair(w, h, d, seed + k) for k in range(2)]
-    frames = [(torch.from_numpy(l).cuda(), torch.from_numpy(rt).cuda()) for l, rt in pairs]
-    torch.cuda.synchronize()
-    get = lambda f: frames[f % 2]                                     # noqa: E731
+    get, _ = _inputs(S, torch, w, h, d, seed, None, B)
     pipe.run(max(args.warmup, 1), get)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -218,7 +224,8 @@ def run_tile_rank_alone(args, spec, WORKLOADS):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     eng.close()
-    print(json.dumps({"tile_rank_alone": spec, "lead": lead, "slots": slots, "workload": args.workload, "rows": tile_rows(h, n)[r], "frames": args.steps,
-                      "ms_per_frame": round(el / args.steps * 1e3, 4), "fps_if_this_rank_were_the_slowest": round(args.steps / el, 2),
+    print(json.dumps({"tile_rank_alone": spec, "lead": lead, "slots": slots, "workload": args.workload, "rows": tile_rows(h, n)[r], "frames": args.steps * B,
+                      "frames_per_step": B, "ms_per_frame": round(el / (args.steps * B) * 1e3, 4),
+                      "fps_if_this_rank_were_the_slowest": round(args.steps * B / el, 2),
                       "note": "one rank's share of an N-rank pipeline alone on one GPU, exchanges skipped: a projection input, not a result"}),
           flush=True)

@@ -253,6 +253,7 @@ class SlotEngine:
     def frame_map(self, slot): raise NotImplementedError                     # [H][W] float32 tensor of the slot
     def post(self, slot): raise NotImplementedError                          # speckle + median on frame_map(slot), in place
     def exchange(self, dist, ops, slots): raise NotImplementedError          # ops: [("send"|"recv", tensor, peer)]
+    def row_views(self, slot, r0, r1): return [self.frame_map(slot)[r0:r1]]  # contiguous tensors holding rows [r0, r1) of the slot's map(s)
     def done(self, slot): return None                                        # event after the slot's last queued work
     def drain(self): pass                                                    # host waits for everything queued
 
@@ -261,21 +262,21 @@ class DeviceSlotEngine(SlotEngine):
     """The product engine: `slots` SGMInstances of this rank's GPU, each restricted to the rank's rows (its planes hold
     only those rows), each on its own HIP stream; a communication stream for the exchanges; HIP events in between."""
 
-    def __init__(self, device: int, width: int, height: int, option, rows: Tuple[int, int], slots: int, host_staged: bool):
+    def __init__(self, device: int, width: int, height: int, option, rows: Tuple[int, int], slots: int, host_staged: bool, batch: int = 1):
         import torch
         from .sgm import SGMInstance
         self.torch = torch
         self.dev = torch.device("cuda", device)
-        self.w, self.h, self.rows, self.option, self.slots = width, height, rows, option, slots
+        self.w, self.h, self.rows, self.option, self.slots, self.batch = width, height, rows, option, slots, batch
         self.host_staged = host_staged              # gloo moves host tensors (rehearsals on a box whose ranks share one GPU)
         self.inst, self.stream, self.maps, self.bufs, self.keep = [], [], [], [], [None] * slots
         for _ in range(slots):
-            i = SGMInstance(device)
+            i = SGMInstance(device, batch=batch)         # batch > 1: a slot is a batch of frames ([B][H][W] images and maps)
             if not (i.set_rows(*rows) and i.reset(width, height, option)):
                 raise RuntimeError("sgm_set_rows / sgm_reset failed")
             self.inst.append(i)
             self.stream.append(torch.cuda.ExternalStream(i.stream, device=self.dev))
-            self.maps.append(torch.empty((height, width), dtype=torch.float32, device=self.dev))
+            self.maps.append(torch.empty((batch, height, width) if batch > 1 else (height, width), dtype=torch.float32, device=self.dev))
             n = i.tile_boundary_bytes()
             self.bufs.append({(f, inc): torch.empty(n, dtype=torch.uint8, device=self.dev) for f in (True, False) for inc in (True, False)})
         self.comm = torch.cuda.Stream(device=self.dev)
@@ -311,6 +312,10 @@ class DeviceSlotEngine(SlotEngine):
 
     def frame_map(self, slot):
         return self.maps[slot]
+
+    def row_views(self, slot, r0, r1):
+        m = self.maps[slot]
+        return [m[r0:r1]] if self.batch == 1 else [m[b, r0:r1] for b in range(self.batch)]
 
     def post(self, slot):
         self._ok(self.inst[slot].tile_post(self.maps[slot].data_ptr()), "sgm_tile_post")
@@ -425,12 +430,12 @@ class TilePipeline:
                     ops.append(("recv", e.boundary(slot(s + 1 - (N - 1 - r)), False, True), r + 1)); touched.add(slot(s + 1 - (N - 1 - r)))
                 h = s - (N - 1)
                 if valid(h):
-                    owner, m = h % N, e.frame_map(slot(h))
+                    owner = h % N
                     touched.add(slot(h))
                     if r != owner:
-                        ops.append(("send", m[self.rows[r][0]:self.rows[r][1]], owner))
+                        ops += [("send", v, owner) for v in e.row_views(slot(h), *self.rows[r])]
                     else:
-                        ops += [("recv", m[self.rows[k][0]:self.rows[k][1]], k) for k in range(N) if k != r]
+                        ops += [("recv", v, k) for k in range(N) if k != r for v in e.row_views(slot(h), *self.rows[k])]
                 e.exchange(self.dist, ops, sorted(touched))
             step_done.append(e.done(slot(step)) if throttle else None)
         e.drain()

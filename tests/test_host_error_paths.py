@@ -356,3 +356,42 @@ def test_platform_frame_entry_stage_order_and_errors(host):
     assert L.sgm_set_rows(s, 0, 10) and L.sgm_reset(s, 48, 20, C.byref(opt))
     assert not L.sgm_match_planes(s, *args)
     L.sgm_destroy(s)
+
+
+def test_row_tiles_of_a_batch(host):
+    """sgm_set_batch on a row-tile instance: every tile call covers the same rows of B frames -- the hand-over holds B rows per
+    direction of the sweep and moves in one launch, like every stage."""
+    import soc_project_stereo_matching_amd as S
+    L = host
+    L.sgm_set_rows.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.sgm_set_rows.restype = C.c_bool
+    L.sgm_set_batch.argtypes = [C.c_void_p, C.c_int]
+    L.sgm_set_batch.restype = C.c_bool
+    L.sgm_tile_boundary_bytes.argtypes = [C.c_void_p]
+    L.sgm_tile_boundary_bytes.restype = C.c_size_t
+    for f in (L.sgm_tile_begin,):
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        f.restype = C.c_bool
+    for f in (L.sgm_tile_export_boundary, L.sgm_tile_import_boundary):
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        f.restype = C.c_bool
+    L.sgm_tile_sweep.argtypes = [C.c_void_p, C.c_int]
+    L.sgm_tile_sweep.restype = C.c_bool
+    L.sgm_tile_finish.argtypes = [C.c_void_p, C.c_void_p]
+    L.sgm_tile_finish.restype = C.c_bool
+    w, h, d, B = 48, 20, 16, 3
+    opt = S.default_option(d)
+    s = L.sgm_create(0)
+    assert L.sgm_set_batch(s, B) and L.sgm_set_rows(s, 5, 12) and L.sgm_reset(s, w, h, C.byref(opt))
+    assert L.sgm_tile_boundary_bytes(s) == B * 3 * w * 32                  # Dp = 32 for D = 16
+    img = np.zeros((B, h, w), np.uint8)
+    buf = np.zeros(B * 3 * w * 32, np.uint8)
+    out = np.zeros((B, h, w), np.float32)
+    L.stub_clear()
+    assert L.sgm_tile_begin(s, img.ctypes.data, img.ctypes.data)
+    assert L.sgm_tile_import_boundary(s, 1, buf.ctypes.data) and L.sgm_tile_sweep(s, 1) and L.sgm_tile_export_boundary(s, 1, buf.ctypes.data)
+    assert L.sgm_tile_finish(s, out.ctypes.data)
+    names = [n for n, _ in log(L, drop=("sync", "alloc", "memset", "h2d", "d2h"))]
+    assert names == ["census", "aggregate", "rows_in", "aggregate", "rows_out", "sum_wta_lr", "lrcheck"]
+    assert [a for n, a in log(L) if n.startswith("rows_")] == [3 * B, 3 * B]      # one launch moves 3 directions x B frames
+    L.sgm_destroy(s)

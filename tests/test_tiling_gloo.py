@@ -177,6 +177,9 @@ class ToySlotEngine:
     def frame_map(self, slot):
         return self.maps[slot]
 
+    def row_views(self, slot, r0, r1):
+        return [self.maps[slot][r0:r1]]
+
     def post(self, slot):
         assert (self.maps[slot] != -7).all(), "a row of another rank never arrived"
         # owners finish their frames at different speeds: frames then complete out of order across the ranks
