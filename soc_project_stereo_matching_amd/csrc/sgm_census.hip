@@ -10,9 +10,12 @@
 #define CEN_BW 64
 #define CEN_BH 16
 #define CEN_LD 72                                                       // LDS row stride in bytes (68 used)
+// need (row tiles): one byte per 64 x 16 block of the image, 0 = nobody on this GPU reads the block's census words
 __global__ __launch_bounds__(256) void sgm_census_k(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
-                                                    uint32_t* __restrict__ cl, uint32_t* __restrict__ cr, int W, int H)
+                                                    uint32_t* __restrict__ cl, uint32_t* __restrict__ cr, int W, int H,
+                                                    const uint8_t* __restrict__ need)
 {
+    if (need && !need[blockIdx.y * gridDim.x + blockIdx.x]) return;
     __shared__ uint8_t tile[(CEN_BH + 4) * CEN_LD];
     const size_t frame_px = (size_t)(blockIdx.z >> 1) * W * H;         // batch: z = 2 * frame + image
     const uint8_t* img = ((blockIdx.z & 1) ? right : left) + frame_px;
@@ -178,12 +181,18 @@ size_t sgmd_census_slack(const sgmd_geom* g)
     return (((size_t)g->dmin + g->Dp + 8) * sizeof(uint32_t) + 255) & ~(size_t)255;
 }
 
-int sgmd_census(int ord, void* stream, const sgmd_geom* g, const void* left, const void* right, void* cl, void* cr)
+void sgmd_census_blocks(const sgmd_geom* g, int* blocks_x, int* blocks_y)
+{
+    *blocks_x = (g->W + CEN_BW - 1) / CEN_BW;
+    *blocks_y = (g->H + CEN_BH - 1) / CEN_BH;
+}
+
+int sgmd_census(int ord, void* stream, const sgmd_geom* g, const void* left, const void* right, void* cl, void* cr, const void* need)
 {
     HIP_TRY(hipSetDevice(ord));
     dim3 grid((g->W + CEN_BW - 1) / CEN_BW, (g->H + CEN_BH - 1) / CEN_BH, 2 * g->B);
     hipLaunchKernelGGL(sgm_census_k, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)left,
-                       (const uint8_t*)right, (uint32_t*)cl, (uint32_t*)cr, g->W, g->H);
+                       (const uint8_t*)right, (uint32_t*)cl, (uint32_t*)cr, g->W, g->H, (const uint8_t*)need);
     HIP_TRY(hipGetLastError());
     return 0;
 }

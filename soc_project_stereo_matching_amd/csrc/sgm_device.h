@@ -80,8 +80,11 @@ typedef struct {
 /* ---- stage launchers (all asynchronous on `stream`) ---- */
 
 /* 5x5 census of both images; border = 0.  SemiGlobalMatching.c:134-159 */
+/* need: NULL, or one byte per block of the sgmd_census_blocks grid (row-major): 0 = leave the block's words as they are (a
+ * row-tile instance only needs its own rows and the pixels the four anomalous lines read) */
 int sgmd_census(int ord, void* stream, const sgmd_geom* g, const void* left, const void* right,
-                void* census_l, void* census_r);
+                void* census_l, void* census_r, const void* need);
+void sgmd_census_blocks(const sgmd_geom* g, int* blocks_x, int* blocks_y);     /* blocks of 64 x 16 pixels */
 
 /* Hamming matching cost volume, u8 [H][W][Dp].  SemiGlobalMatching.c:161-196 */
 int sgmd_cost(int ord, void* stream, const sgmd_geom* g, const void* census_l, const void* census_r, void* cost);

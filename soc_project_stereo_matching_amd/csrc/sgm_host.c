@@ -78,6 +78,9 @@ struct sgm_instance {
     void *d_snap_wta, *d_snap_lr, *d_snap_speckle, *d_totals, *d_median_scratch;
     void *d_census64_l, *d_census64_r;   /* u64 census words of the wide windows (allocated on first use) */
     size_t cap_census64;
+    void* d_census_need;                 /* row tiles: which 64 x 16 blocks of the census this instance reads (sgmd_census) */
+    size_t cap_census_need;
+    int need_key[7];                     /* W, H, rows, dmin, Dp, ndirs the map was built for */
     void *d_bgr, *d_depth, *h_bgr;       /* a test-platform frame's six colour planes, its depth map, pinned staging (first use) */
     size_t cap_bgr;
     size_t plane_bytes;
@@ -197,7 +200,7 @@ static void free_device_buffers(sgm_instance* s)
     void** all[] = {&s->d_left, &s->d_right, &s->d_census_l, &s->d_census_r_alloc, &s->d_cost, &s->d_planes_alloc, &s->d_extras,
                     &s->d_S, &s->d_disp, &s->d_disp_r, &s->d_labels, &s->d_sizes, &s->d_lut, &s->d_row_extras,
                     &s->d_row_count, &s->d_snap_wta, &s->d_snap_lr, &s->d_snap_speckle, &s->d_totals,
-                    &s->d_median_scratch, &s->d_census64_l, &s->d_census64_r, &s->d_bgr, &s->d_depth};
+                    &s->d_median_scratch, &s->d_census64_l, &s->d_census64_r, &s->d_bgr, &s->d_depth, &s->d_census_need};
     for (size_t i = 0; i < sizeof all / sizeof all[0]; ++i) {
         sgmd_free(s->device, *all[i]);
         *all[i] = NULL;
@@ -208,6 +211,8 @@ static void free_device_buffers(sgm_instance* s)
     sgmd_free_pinned(s->device, s->h_bgr);
     s->h_left = s->h_right = s->h_disp = s->h_bgr = NULL;
     s->cap_px = s->cap_planes = s->cap_S = s->cap_cost = s->cap_extras = s->cap_median = s->cap_census64 = s->cap_bgr = 0;
+    s->cap_census_need = 0;
+    s->need_key[0] = 0;
     s->cap_H = s->cap_row_cap = 0;
     s->tab_W = s->tab_H = 0;
 }
@@ -300,6 +305,52 @@ int sgm_last_timing(sgm_instance* s, const char** names, float* ms, int max_entr
         if (ms) ms[n] = s->last_ms[i];
     }
     return n;
+}
+
+/* Row tiles: the census words this instance reads are those of its own rows (horizontal lines, the sweeps, the cost sum's
+ * recomputation) and, on every row of the frame, the pixel an anomalous line visits with the Dp words to its left.  Everything
+ * else of the replicated images is skipped: sgmd_census takes one byte per 64 x 16 block.  (The aggregation's masked and
+ * prefetched reads beyond that see whatever the buffer holds, as they always did at row starts.) */
+static bool upload_census_need(sgm_instance* s)
+{
+    const int W = s->g.W, H = s->g.H;
+    const int key[7] = {W, H, s->g.row_begin, s->g.row_end, s->g.dmin, s->g.Dp, s->paths.ndirs};
+    if (s->d_census_need && memcmp(key, s->need_key, sizeof key) == 0) return true;
+    int bx, by;
+    sgmd_census_blocks(&s->g, &bx, &by);
+    const size_t n = (size_t)bx * by;
+    uint8_t* need = (uint8_t*)calloc(n, 1);
+    int32_t* pix = (int32_t*)malloc(sizeof(int32_t) * (size_t)(W > H ? W : H));
+    if (!need || !pix) { free(need); free(pix); FAIL("out of host memory"); }
+    const int bw = 64, bh = 16;                               /* sgmd_census_blocks */
+    for (int r = s->g.row_begin / bh; r <= (s->g.row_end - 1) / bh; ++r) memset(need + (size_t)r * bx, 1, (size_t)bx);
+    if (s->paths.ndirs > 4) {
+        const int back = s->g.dmin + s->g.Dp + 64;            /* words left of the pixel: range + the widest vector load */
+        for (int d = 4; d < 8; ++d) {
+            const int cnt = walk_line(W, H, k_dir_dx[d], k_dir_dy[d], s->paths.anom_line[d], pix);
+            for (int k = 0; k < cnt; ++k) {
+                const int y = pix[k] / W, x = pix[k] % W;
+                const int c0 = (x - back < 0 ? 0 : x - back) / bw, c1 = x / bw;
+                memset(need + (size_t)(y / bh) * bx + c0, 1, (size_t)(c1 - c0 + 1));
+                /* a window that starts left of column 0 continues at the end of the row above (masked, but keep it defined) */
+                if (x - back < 0 && y > 0) need[(size_t)((y - 1) / bh) * bx + bx - 1] = 1;
+            }
+        }
+    }
+    free(pix);
+    bool ok = true;
+    if (n > s->cap_census_need || !s->d_census_need) {
+        sync_streams(s);
+        sgmd_free(s->device, s->d_census_need);
+        s->d_census_need = NULL;
+        ok = sgmd_alloc(s->device, &s->d_census_need, n) == 0;
+        s->cap_census_need = ok ? n : 0;
+    }
+    ok = ok && sgmd_h2d_async(s->device, s->stream, s->d_census_need, need, n) == 0 && sync_streams(s) == 0;
+    free(need);
+    if (!ok) FAIL("uploading the census block map failed");
+    memcpy(s->need_key, key, sizeof key);
+    return true;
 }
 
 /* Build the per-row table of anomalous-line visits and upload it together with the P2 table. */
@@ -538,6 +589,8 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
         s->tab_p1 = option->p1; s->tab_p2 = option->p2_init;
     }
 
+    if (s->tile_end != 0 && !s->census_w && !upload_census_need(s)) return false;
+
     s->s_is_zero = true;                                         /* .c:57: memset of cost_aggr, done lazily */
     s->s_pending = false;
     {
@@ -618,7 +671,15 @@ static int sum_and_wta(sgm_instance* s, void* d_out, bool with_marks)
 /* .c:82-83 (+ .c:89 for the wide census windows, whose cost is materialised): census of both images */
 static int prepare_costs(sgm_instance* s, const void* d_left, const void* d_right)
 {
-    if (!s->census_w) return sgmd_census(s->device, s->stream, &s->g, d_left, d_right, s->d_census_l, s->d_census_r);
+    if (!s->census_w) {
+        const bool tiled = s->tile_end != 0 && !s->keep_stages;          /* stage read-back wants the whole census */
+        if (tiled && getenv("SGM_DEBUG_POISON_CENSUS")) {                /* tests: a read of a skipped block must not go unnoticed */
+            const size_t bytes = (size_t)s->g.B * s->g.W * s->g.H * 4;
+            if (sgmd_memset_async(s->device, s->stream, s->d_census_l, 0xA5, bytes) != 0 ||
+                sgmd_memset_async(s->device, s->stream, s->d_census_r, 0x5A, bytes) != 0) return -1;
+        }
+        return sgmd_census(s->device, s->stream, &s->g, d_left, d_right, s->d_census_l, s->d_census_r, tiled ? s->d_census_need : NULL);
+    }
     const size_t need = (size_t)s->g.B * s->g.W * s->g.H * 8;
     if (need > s->cap_census64 || !s->d_census64_l) {
         sync_streams(s);

@@ -64,8 +64,9 @@ void sgmd_timer_destroy(int o, void* t) { (void)o; free(t); }
 int sgmd_timer_mark(int o, void* t, void* st, int i) { (void)o; (void)t; (void)st; (void)i; return 0; }
 int sgmd_timer_elapsed(int o, void* t, int a, int b, float* ms) { (void)o; (void)t; (void)a; (void)b; *ms = 0.f; return 0; }
 
-int sgmd_census(int o, void* st, const sgmd_geom* g, const void* l, const void* r, void* cl, void* cr)
-{ (void)o; (void)st; (void)l; (void)r; (void)cl; (void)cr; return note("census", g->B); }
+int sgmd_census(int o, void* st, const sgmd_geom* g, const void* l, const void* r, void* cl, void* cr, const void* need)
+{ (void)o; (void)st; (void)l; (void)r; (void)cl; (void)cr; (void)need; return note("census", g->B); }
+void sgmd_census_blocks(const sgmd_geom* g, int* bx, int* by) { *bx = (g->W + 63) / 64; *by = (g->H + 15) / 16; }
 int sgmd_cost(int o, void* st, const sgmd_geom* g, const void* cl, const void* cr, void* c)
 { (void)o; (void)st; (void)g; (void)cl; (void)cr; (void)c; return note("cost", 0); }
 int sgmd_census_window(int o, void* st, const sgmd_geom* g, int cw, int ch, const void* l, const void* r, void* cl, void* cr)

@@ -34,6 +34,14 @@ def _engines(w, h, opt, n, honor4=False):
     return out
 
 
+@pytest.fixture(autouse=True)
+def poisoned_census(monkeypatch):
+    """A row-tile instance computes the census of its own rows and of the pixels the anomalous lines read, nothing else of the
+    replicated images; with this switch the library fills the census buffers with a pattern first, so a kernel that reads a word
+    nobody computed shows up as a wrong result instead of passing on stale data."""
+    monkeypatch.setenv("SGM_DEBUG_POISON_CENSUS", "1")
+
+
 @pytest.mark.parametrize("case", [
     # W, H, dmin, dmax, tiles, option overrides
     (130, 47, 2, 50, 2, {}),                       # padded disparity range, odd sizes
