@@ -64,7 +64,7 @@ def run_tiles(args, init_dist, WORKLOADS, golden_digests):
     w, h, d, seed = WORKLOADS[args.workload]
     opt = S.default_option(d)
     lead, B = args.tile_lead, max(1, args.batch or 1)
-    slots = max(world + 2 + lead, args.in_flight or 0)
+    slots = max(TilePipeline.slots_needed(world, lead), args.in_flight or 0)
     eng = DeviceSlotEngine(local_rank, w, h, opt, tile_rows(h, world)[rank], slots, host_staged=(world > 1 and backend != "nccl"), batch=B)
     pipe = TilePipeline(eng, rank, world, h, dist=dist if world > 1 else None, lead=lead)
 
@@ -152,7 +152,7 @@ def run_tiles_in_process(args, ranks, WORKLOADS, golden_digests):
     w, h, d, seed = WORKLOADS[args.workload]
     opt = S.default_option(d)
     lead, B = args.tile_lead, max(1, args.batch or 1)
-    slots = max(ranks + 2 + lead, args.in_flight or 0)
+    slots = max(TilePipeline.slots_needed(ranks, lead), args.in_flight or 0)
     group = InProcessGroup(ranks)
     digests = golden_digests(args.workload)
     get, seeds_of = _inputs(S, torch, w, h, d, seed, digests, B)
@@ -213,7 +213,7 @@ def run_tile_rank_alone(args, spec, WORKLOADS):
     w, h, d, seed = WORKLOADS[args.workload]
     opt = S.default_option(d)
     lead, B = args.tile_lead, max(1, args.batch or 1)
-    slots = max(n + 2 + lead, args.in_flight or 0)
+    slots = max(TilePipeline.slots_needed(n, lead), args.in_flight or 0)
     eng = DeviceSlotEngine(0, w, h, opt, tile_rows(h, n)[r], slots, host_staged=False, batch=B)
     pipe = TilePipeline(eng, r, n, h, dist=NullGroup(), lead=lead)
     get, _ = _inputs(S, torch, w, h, d, seed, None, B)

@@ -228,14 +228,18 @@ def match_tiled_in_process(engines, left, right):
 #     tile_begin            of frame s                    (census, horizontal paths of its rows, anomalous lines)
 #     forward sweep         of frame s - r                (needs the hand-over rank r-1 produced at step s-1)
 #     backward sweep        of frame s - (N-1-r)          (needs the hand-over rank r+1 produced at step s-1)
+#     -- the exchange of the step (below) is queued here --
 #     tile_finish           of frame s - max(r, N-1-r)    (both sweeps of that frame are done: cost sum, WTA, LR check)
-#     speckle + median      of frame s - N, on its owner rank (s - N) mod N only (not on every rank)
+#     speckle + median      of frame s - N - 1, on its owner rank only (not on every rank)
 #
 # and between steps s and s+1 ONE grouped exchange per rank (torch.distributed.batch_isend_irecv: a single RCCL group,
 # so the sends and receives of neighbouring ranks cannot deadlock on each other): forward hand-over to r+1, backward
-# hand-over to r-1, and the disparity rows of frame s-(N-1) -- finished on every rank by then -- to its owner.  Every
-# rank issues the same step sequence, so each send meets its receive in the same exchange.  A frame lives in one of R
-# >= N+2 slots per rank (a slot = an SGMInstance restricted to the rank's rows, its stream, its hand-over buffers and a
+# hand-over to r-1, and the disparity rows of frame s-N -- finished on every rank in an earlier step -- to its owner.
+# Every rank issues the same step sequence, so each send meets its receive in the same exchange.  The exchange is queued
+# before the step's tile_finish: the next step's sweeps wait for it, and it waits for whatever its slots have queued so
+# far, so a cost sum queued in front of it would sit on the chain sweep -> exchange -> sweep that paces the pipeline
+# (DESIGN.md section 7).  A frame lives in one of R
+# >= N+3 slots per rank (a slot = an SGMInstance restricted to the rank's rows, its stream, its hand-over buffers and a
 # [H][W] disparity map); nothing blocks the host: kernels of a slot are ordered by its stream, exchanges run on a
 # communication stream, and HIP events order the two (slot -> exchange -> slot).  In the steady state every rank does
 # 1/N of every stage of one frame per step; speckle + median of a frame run once, on its owner.
@@ -371,11 +375,16 @@ class TilePipeline:
          `tensor` ([H][W]) is the slot's map: valid after `event` (None = already complete) and until the slot is reused,
          slots - world - 1 steps later -- copy or consume it before."""
 
+    @staticmethod
+    def slots_needed(world: int, lead: int = 0) -> int:
+        """A frame occupies its slot from tile_begin (step f) to the post pass (step f + lead + world + 1)."""
+        return world + 3 + lead
+
     def __init__(self, engine: SlotEngine, rank: int, world: int, height: int, dist=None, lead: int = 0):
         if lead < 0:
             raise ValueError("lead must be >= 0")
-        if engine.slots < world + 2 + lead:
-            raise ValueError(f"{world} ranks with a lead of {lead} need at least {world + 2 + lead} slots per rank, got {engine.slots}")
+        if engine.slots < self.slots_needed(world, lead):
+            raise ValueError(f"{world} ranks with a lead of {lead} need at least {self.slots_needed(world, lead)} slots per rank, got {engine.slots}")
         self.e, self.rank, self.world, self.h, self.dist, self.lead = engine, rank, world, height, dist, lead
         self.rows = tile_rows(height, world)
 
@@ -390,7 +399,7 @@ class TilePipeline:
         valid = lambda f: 0 <= f < F                                 # noqa: E731
         lag = max(r, N - 1 - r)
         step_done = []
-        for step in range(F + N + 1 + K):
+        for step in range(F + N + 2 + K):
             if throttle and step >= throttle and step_done[step - throttle] is not None:
                 step_done[step - throttle].synchronize()             # bound the host's run-ahead
             touched = set()
@@ -409,15 +418,10 @@ class TilePipeline:
                 e.sweep(slot(fr), forward)
                 if not last:
                     e.export_boundary(slot(fr), forward)
-            if valid(s - lag):
-                e.finish(slot(s - lag))
-            p = s - N
-            if valid(p) and p % N == r:
-                e.post(slot(p))
-                if on_result is not None:
-                    on_result(p, e.frame_map(slot(p)), e.done(slot(p)))
-            # ---- the exchange between step s and s + 1 (boundary operations first, then the row gather: neighbouring
-            #      ranks list the operations between them in the same order)
+            # ---- the exchange between step s and s + 1, queued BEFORE this step's tile_finish: it waits for what the slots
+            #      have queued so far, and the next step's sweeps wait for it -- the cost sum of a frame must not sit on that
+            #      chain.  Boundary operations first, then the row gather (neighbouring ranks list the operations between them
+            #      in the same order); the gather is of the frame every rank finished in an EARLIER step (s - N).
             ops = []
             if N > 1:
                 if valid(f) and r < N - 1:
@@ -428,7 +432,7 @@ class TilePipeline:
                     ops.append(("send", e.boundary(slot(g), False, False), r - 1)); touched.add(slot(g))
                 if valid(s + 1 - (N - 1 - r)) and r < N - 1:
                     ops.append(("recv", e.boundary(slot(s + 1 - (N - 1 - r)), False, True), r + 1)); touched.add(slot(s + 1 - (N - 1 - r)))
-                h = s - (N - 1)
+                h = s - N
                 if valid(h):
                     owner = h % N
                     touched.add(slot(h))
@@ -437,6 +441,13 @@ class TilePipeline:
                     else:
                         ops += [("recv", v, k) for k in range(N) if k != r for v in e.row_views(slot(h), *self.rows[k])]
                 e.exchange(self.dist, ops, sorted(touched))
+            if valid(s - lag):
+                e.finish(slot(s - lag))
+            p = s - N - 1
+            if valid(p) and p % N == r:
+                e.post(slot(p))
+                if on_result is not None:
+                    on_result(p, e.frame_map(slot(p)), e.done(slot(p)))
             step_done.append(e.done(slot(step)) if throttle else None)
         e.drain()
 

@@ -209,7 +209,7 @@ def test_slot_pipeline_on_one_rank(oracle, case):
     opt = default_option(d, min_speckle_area=20)
     frames = [oracle.synth_pair(w, h, d, 0x51D0 + k) for k in range(n)]
     dev = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in frames]
-    eng = DeviceSlotEngine(0, w, h, opt, (0, h), world + 2, host_staged=False)
+    eng = DeviceSlotEngine(0, w, h, opt, (0, h), TilePipeline.slots_needed(world), host_staged=False)
     got = {}
 
     def on_result(f, t, ev):
@@ -234,7 +234,7 @@ def _pipe_rank_main(rank, world, port, w, h, d, seed, n_frames, out_path):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     opt = S.default_option(d)
-    eng = DeviceSlotEngine(0, w, h, opt, tile_rows(h, world)[rank], world + 2, host_staged=True)   # every rank on the box's one GPU
+    eng = DeviceSlotEngine(0, w, h, opt, tile_rows(h, world)[rank], TilePipeline.slots_needed(world), host_staged=True)   # every rank on the box's one GPU
     pairs = [S.synth_pair(w, h, d, seed + k) for k in range(n_frames)]
     dev = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in pairs]
 
@@ -302,7 +302,7 @@ def test_pipeline_of_batched_tiles_ranks_as_threads(oracle, case):
         eng = None
         try:
             torch.cuda.set_device(0)
-            eng = DeviceSlotEngine(0, w, h, opt, tile_rows(h, ranks)[r], ranks + 2 + lead, host_staged=False, batch=B)
+            eng = DeviceSlotEngine(0, w, h, opt, tile_rows(h, ranks)[r], TilePipeline.slots_needed(ranks, lead), host_staged=False, batch=B)
             for i in eng.inst:
                 i.set_honor_num_paths(bool(extra.get("paths4")))
                 i.set_reference_view(bool(extra.get("right")))

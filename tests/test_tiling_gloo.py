@@ -214,7 +214,7 @@ def _pipe_worker(rank, world, port, h, w, n_frames, out_path, lead=0):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     l, r = _images(h, w)
-    eng = ToySlotEngine(h, w, tile_rows(h, world)[rank], world + 2 + lead)
+    eng = ToySlotEngine(h, w, tile_rows(h, world)[rank], TilePipeline.slots_needed(world, lead))
     pipe = TilePipeline(eng, rank, world, h, dist=dist, lead=lead)
     got = {}
     import time
@@ -226,7 +226,7 @@ def _pipe_worker(rank, world, port, h, w, n_frames, out_path, lead=0):
         assert f % world == rank                                    # only a frame's owner runs its post pass
         np.save(f"{out_path}.rep{rep}.f{f}.npy", t.numpy())
     assert sum(1 for e in eng.log if e[0] == "post") == 2 * len(range(rank, n_frames, world))
-    assert eng.exchanges <= 2 * (n_frames + world + 1 + lead)       # one grouped exchange per step
+    assert eng.exchanges <= 2 * (n_frames + world + 2 + lead)       # one grouped exchange per step
     dist.barrier()
     dist.destroy_process_group()
 
@@ -259,16 +259,16 @@ def test_pipeline_single_rank_and_slot_guard():
     h, w = 19, 11
     l, r = _images(h, w)
     with pytest.raises(ValueError):
-        TilePipeline(ToySlotEngine(h, w, (0, h), 2), 0, 1, h)       # needs world + 2 slots
+        TilePipeline(ToySlotEngine(h, w, (0, h), 3), 0, 1, h)       # needs world + 3 slots
     with pytest.raises(ValueError):
-        TilePipeline(ToySlotEngine(h, w, (0, h), 4), 0, 1, h, lead=2)   # ... + lead
-    eng = ToySlotEngine(h, w, (0, h), 3)
+        TilePipeline(ToySlotEngine(h, w, (0, h), 5), 0, 1, h, lead=2)   # ... + lead
+    eng = ToySlotEngine(h, w, (0, h), 4)
     got = {}
     TilePipeline(eng, 0, 1, h).run(4, lambda f: (torch.from_numpy(l) + f, torch.from_numpy(r)),
                                    lambda f, t, ev: got.__setitem__(f, t.clone()))
     assert sorted(got) == [0, 1, 2, 3]
     got2 = {}
-    TilePipeline(ToySlotEngine(h, w, (0, h), 5), 0, 1, h, lead=2).run(4, lambda f: (torch.from_numpy(l) + f, torch.from_numpy(r)),
+    TilePipeline(ToySlotEngine(h, w, (0, h), 6), 0, 1, h, lead=2).run(4, lambda f: (torch.from_numpy(l) + f, torch.from_numpy(r)),
                                                                       lambda f, t, ev: got2.__setitem__(f, t.clone()))
     assert sorted(got2) == [0, 1, 2, 3] and all(torch.equal(got[f], got2[f]) for f in got)
     for f in range(4):
@@ -290,7 +290,7 @@ def test_pipeline_ranks_as_threads_of_one_process(world, n_frames, lead):
 
     def rank_main(rank):
         try:
-            eng = ToySlotEngine(h, w, tile_rows(h, world)[rank], world + 2 + lead)
+            eng = ToySlotEngine(h, w, tile_rows(h, world)[rank], TilePipeline.slots_needed(world, lead))
             TilePipeline(eng, rank, world, h, dist=group.view(rank), lead=lead).run(
                 n_frames, lambda f: (torch.from_numpy(l) + f, torch.from_numpy(r)), lambda f, t, ev: got.__setitem__(f, (rank, t.clone())))
         except Exception as exc:                                    # noqa: BLE001

@@ -58,7 +58,7 @@ def pipe_case(orc, rng, w, h, d, opt, seed, kw):
         eng = None
         try:
             torch.cuda.set_device(0)
-            eng = DeviceSlotEngine(0, w, h, opt, tile_rows(h, ranks)[r], ranks + 2 + lead, host_staged=False, batch=B)
+            eng = DeviceSlotEngine(0, w, h, opt, tile_rows(h, ranks)[r], TilePipeline.slots_needed(ranks, lead), host_staged=False, batch=B)
 
             def on_result(f, t, ev):
                 ev.synchronize()
