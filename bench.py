@@ -538,7 +538,7 @@ def main():
     ap.add_argument("--tile-ranks-in-process", type=int, default=0,
                     help="tiles mode on ONE GPU: this many tile ranks as threads of one process (device copies stand in for xGMI): "
                          "what the pipeline schedule itself costs against --mode tiles with one rank; not a multi-GPU measurement")
-    ap.add_argument("--tile-lead", type=int, default=int(os.environ.get("SGM_TILE_LEAD", "0")),
+    ap.add_argument("--tile-lead", type=int, default=int(os.environ.get("SGM_TILE_LEAD", "2")),
                     help="tiles mode: steps tile_begin of a frame is queued ahead of its first sweep (tiling.TilePipeline lead)")
     ap.add_argument("--tile-rank-alone", default=None, metavar="r/N",
                     help="tiles mode: rank r of an N-rank pipeline alone on this GPU with the exchanges skipped: its time per frame "

@@ -372,13 +372,14 @@ class TilePipeline:
     """The step sequence above for one rank.  run(n_frames, get_frame, on_result):
          get_frame(f)  -> (left, right) of frame f (every rank holds the whole images);
          on_result(f, tensor, event) is called on the OWNER rank of frame f (f mod world) once speckle + median are queued;
-         `tensor` ([H][W]) is the slot's map: valid after `event` (None = already complete) and until the slot is reused,
-         slots - world - 1 steps later -- copy or consume it before."""
+         `tensor` ([H][W]) is the slot's map: valid after `event` (None = already complete) and until the slot is reused
+         (slots - slots_needed(world, lead) + 1 steps later) -- copy or consume it before."""
 
     @staticmethod
     def slots_needed(world: int, lead: int = 0) -> int:
-        """A frame occupies its slot from tile_begin (step f) to the post pass (step f + lead + world + 1)."""
-        return world + 3 + lead
+        """A frame occupies its slot from tile_begin (step f) to the post pass (step f + lead + world + 1; with one rank there is
+        no row gather to wait for and the post pass follows tile_finish in step f + lead)."""
+        return (world + 3 if world > 1 else 2) + lead
 
     def __init__(self, engine: SlotEngine, rank: int, world: int, height: int, dist=None, lead: int = 0):
         if lead < 0:
@@ -443,7 +444,7 @@ class TilePipeline:
                 e.exchange(self.dist, ops, sorted(touched))
             if valid(s - lag):
                 e.finish(slot(s - lag))
-            p = s - N - 1
+            p = s - N - 1 if N > 1 else s                            # one rank: nothing to gather, post follows finish
             if valid(p) and p % N == r:
                 e.post(slot(p))
                 if on_result is not None:

@@ -259,16 +259,16 @@ def test_pipeline_single_rank_and_slot_guard():
     h, w = 19, 11
     l, r = _images(h, w)
     with pytest.raises(ValueError):
-        TilePipeline(ToySlotEngine(h, w, (0, h), 3), 0, 1, h)       # needs world + 3 slots
+        TilePipeline(ToySlotEngine(h, w, (0, h), 1), 0, 1, h)       # one rank needs 2 slots
     with pytest.raises(ValueError):
-        TilePipeline(ToySlotEngine(h, w, (0, h), 5), 0, 1, h, lead=2)   # ... + lead
-    eng = ToySlotEngine(h, w, (0, h), 4)
+        TilePipeline(ToySlotEngine(h, w, (0, h), 3), 0, 1, h, lead=2)   # ... + lead
+    eng = ToySlotEngine(h, w, (0, h), 2)
     got = {}
     TilePipeline(eng, 0, 1, h).run(4, lambda f: (torch.from_numpy(l) + f, torch.from_numpy(r)),
                                    lambda f, t, ev: got.__setitem__(f, t.clone()))
     assert sorted(got) == [0, 1, 2, 3]
     got2 = {}
-    TilePipeline(ToySlotEngine(h, w, (0, h), 6), 0, 1, h, lead=2).run(4, lambda f: (torch.from_numpy(l) + f, torch.from_numpy(r)),
+    TilePipeline(ToySlotEngine(h, w, (0, h), 4), 0, 1, h, lead=2).run(4, lambda f: (torch.from_numpy(l) + f, torch.from_numpy(r)),
                                                                       lambda f, t, ev: got2.__setitem__(f, t.clone()))
     assert sorted(got2) == [0, 1, 2, 3] and all(torch.equal(got[f], got2[f]) for f in got)
     for f in range(4):

@@ -30,7 +30,7 @@ def main():
     for b in (1, 4, 8):
         steps = str((240 if kitti else 48) // b + 8)
         common = ["--workload", wl, "--batch", str(b), "--steps", steps, "--warmup", "4"]
-        one = run(common, '"metric"')
+        one = run(common + ["--tile-lead", "0", "--in-flight", "3"], '"metric"')   # one rank: nothing to lead; three slots of whole frames
         entry = {"frames_per_step": b,
                  "one_rank": {"fps": one["fps"], "frames_verified": one["frames_verified"], "frames_mismatched": one["frames_mismatched"]},
                  "ranks_in_process": [], "rank_alone": []}
