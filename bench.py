@@ -14,7 +14,9 @@ rank processes its own K batches (weak scaling, no data-path collective); `value
 
 --mode tiles.  Every frame is cut into N row tiles, one per GPU (soc_project_stereo_matching_amd/tiling.py): boundary
 path costs are handed from rank to rank, several frames are in flight so that the ranks work as a pipeline, the rows are
-gathered on the frame's owner rank, which runs speckle removal + median.  A step is one frame; strong scaling.
+gathered on the frame's owner rank, which runs speckle removal + median.  A step is one frame (--batch B: the same tile of B
+frames per launch and per hand-over); strong scaling.  On ONE GPU: --tile-ranks-in-process N runs N ranks as threads (device copies
+for the hand-overs), --tile-rank-alone r/N one rank's share with the exchanges skipped (tools/tiles_schedule_cost.py).
 
 Every frame of the LAST timed batch of every in-flight instance is hashed against the digest the reference's own C
 produced for that seed (tests/golden/bench_frames.json): `frames_verified`.
