@@ -93,3 +93,30 @@ def test_sgm_mode_depth_bit_exact(exe, oracle):
         got = srv.results[k]
         assert np.array_equal(np.isnan(got), np.isnan(want))
         assert np.array_equal(got[~np.isnan(got)].view(np.uint32), want[~np.isnan(want)].view(np.uint32)), k
+
+
+def test_client_is_asan_clean_with_the_stub_device(tmp_path, oracle):
+    """sgm_board_client.c + the C host under AddressSanitizer / UBSan, linked with the stub device layer (no GPU; the maps it
+    returns are meaningless): socket framing, pinned-buffer lifetime and the platform-frame entry for frames of two sizes in one
+    session (buffers re-sized), then the server closing the connection."""
+    import shutil
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    csrc = os.path.join(ROOT, "soc_project_stereo_matching_amd", "csrc")
+    exe_asan = str(tmp_path / "board_client_asan")
+    subprocess.check_call(["gcc", "-O1", "-g", "-std=c11", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I", csrc,
+                           "-o", exe_asan, os.path.join(csrc, "sgm_board_client.c"), os.path.join(csrc, "sgm_host.c"),
+                           os.path.join(ROOT, "tests", "stub_device.c"), "-lm"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:exitcode=99")
+    env.pop("LD_PRELOAD", None)
+    frames = bgr_frames(2, 96, 40, 16, oracle, 4300) + bgr_frames(2, 64, 24, 16, oracle, 4400)
+    for extra in ([], ["--placeholder-gray"], ["--max-frames", "3"]):
+        srv = PlatformServer(frames, load_npz("platform_calib.npz")["packed"].tobytes())
+        out = subprocess.run([exe_asan, "127.0.0.1", str(srv.port), "--max-disparity", "16"] + extra, capture_output=True, text=True,
+                             env=env, timeout=120)
+        srv.join()
+        assert out.returncode == 0, (extra, out.returncode, out.stderr[-2000:])
+        assert "Sanitizer" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-2000:]
+        assert len(srv.results) == (3 if extra and extra[0] == "--max-frames" else 4)
+        for k, res in srv.results.items():
+            assert res.shape == frames[k][0].shape[:2]
