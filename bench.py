@@ -313,9 +313,12 @@ def run_frames(args):
     B = max(1, args.batch)
     insts = [S.SGMInstance(local_rank, batch=B) for _ in range(n_inst)]
     overlap_post = args.overlap_post if args.overlap_post is not None else int(os.environ.get("SGM_BENCH_OVERLAP_POST", "0"))
+    cu_split = args.cu_split if args.cu_split is not None else os.environ.get("SGM_BENCH_CU_SPLIT", "")
     for i in insts:
         if overlap_post and not i.set_overlap_post(True):
             raise SystemExit("sgm_set_overlap_post failed")
+        if cu_split and not i.set_cu_split(cu_split):
+            raise SystemExit(f"sgm_set_stage_cus failed for {cu_split!r}")
         if not i.reset(w, h, opt):
             raise SystemExit("sgm_reset failed")
         i.enable_timing(True)
@@ -479,7 +482,8 @@ def run_frames(args):
             "config": {"workload": args.workload, "mode": "frames", "width": w, "height": h, "disparity_range": d, "paths": PATHS,
                        "stages": "census+cost+aggregate8+wta+lrcheck+speckle+median", "frames_per_step": B,
                        "frames_per_gpu": args.steps * B, "batches_in_flight_per_gpu": n_inst,
-                       "post_pass_on_second_stream": bool(overlap_post),
+                       "post_pass_on_second_stream": bool(overlap_post) or "post" in cu_split,
+                       "stage_cus_per_xcd": cu_split or None,
                        "sharding": "independent frames per rank, no collective"},
             "roofline": roofline,
             "roofline_sum_wta": sum_roofline,
@@ -551,6 +555,9 @@ def main():
                     help="sgm_set_overlap_post on the bench's instances: LR check / speckle / median of a batch on a second stream "
                          "beside the next batch's aggregation (default: SGM_BENCH_OVERLAP_POST or 0: +1..3 %% fps with two batches in "
                          "flight, +7 %% with one, but the launches then overlap more and the per-launch roofline fractions read lower)")
+    ap.add_argument("--cu-split", default=None, metavar="SPEC",
+                    help="sgm_set_stage_cus on the bench's instances: stage groups on streams and compute units of their own, e.g. "
+                         "'post=0:2,sum=2:8,main=10:22' = first:count CUs of every XCD (count 0: own stream on all CUs)")
     ap.add_argument("--alone", action="store_true",
                     help="after the timed region also time the batches with ONE instance and nothing else on the GPU -> roofline.alone "
                          "(off by default: a kernel trace of the default run then holds the timed configuration only, so rocprofv3's "
@@ -569,6 +576,8 @@ def main():
         if args.tile_ranks_in_process > 1:
             return run_tiles_in_process(args, args.tile_ranks_in_process, WORKLOADS, golden_digests)
         return run_tiles(args, init_dist, WORKLOADS, golden_digests)
+    if args.cu_split or os.environ.get("SGM_BENCH_CU_SPLIT"):
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # up to three streams per instance in flight: no two of them on one hardware queue
     args.workload = args.workload or "kitti_1242x375_d128_p8"
     args.batch = args.batch or 8
     args.in_flight = args.in_flight or 2

@@ -142,6 +142,21 @@ void          sgm_host_free(sgm_instance* s, void* p);
  * changes: the disparity map of sgm_match_device is complete after sgm_synchronize (or sgm_match_wait for the host-pointer
  * form), no longer in stream order of sgm_stream(s).  Off by default; ignored in row-tile mode. */
 bool          sgm_set_overlap_post(sgm_instance* s, int enable);
+/* Stage groups on streams -- and compute units -- of their own.  A match is three groups of kernels with different appetites:
+ * census + path aggregation (VALU-bound, SemiGlobalMatching.c:82-94), cost sum + both winner-take-all passes (HBM-bound,
+ * .c:94-105), LR check + speckle removal + median (latency-bound, a few workgroups, .c:109-120).  When several matches are in
+ * flight on one GPU (two instances, or a stream of matches on one with sgm_set_overlap_post) kernels of different groups share
+ * compute units and slow each other down far more than they gain from the sharing -- the median's serial kernel runs three
+ * times longer next to an aggregation's waves than alone.  sgm_set_stage_cus(s, which, first, count) gives group `which` a HIP
+ * stream of its own whose kernels run only on CUs [first, first + count) of EVERY XCD (MI355X: 32 CUs in each of 8 XCDs; each
+ * XCD keeps its L2 and its path to HBM in play); the groups are ordered by events, results are unchanged.
+ *   count > 0   own stream on those CUs        count == 0  own stream, all CUs       count < 0  back to the default
+ *   which = SGM_STAGE_MAIN: the stream census + aggregation (and every group without a stream of its own) run on; re-created,
+ *   so sgm_stream(s) changes.   SGM_STAGE_POST with count == 0 is sgm_set_overlap_post(s, 1).
+ * As with sgm_set_overlap_post a result is complete after sgm_synchronize / sgm_match_wait, not in stream order of
+ * sgm_stream(s).  Ignored in row-tile mode.  The instance must be idle (the call waits for it). */
+enum { SGM_STAGE_MAIN = 0, SGM_STAGE_SUM = 1, SGM_STAGE_POST = 2 };
+bool          sgm_set_stage_cus(sgm_instance* s, int which, int first_cu_per_xcd, int cus_per_xcd);
 /* The HIP stream (hipStream_t as void*) the instance launches on, e.g. to record events. */
 void*         sgm_stream(sgm_instance* s);
 

@@ -96,6 +96,7 @@ class Oracle:
             f.restype = C.c_bool
         L.sgmo_match.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.sgmo_match.restype = C.c_bool
+        L.sgmo_clear_census.argtypes = [C.c_void_p]
         L.sgmo_stage.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_size_t)]
         L.sgmo_stage.restype = C.c_void_p
         L.sgmo_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
@@ -178,9 +179,15 @@ class Oracle:
         self.lib.sgmo_counters(self.ctx, c)
         return {"oob_dropped": int(c[0]), "u8_wraps": int(c[1])}
 
+    def clear_census(self):
+        """The census statics as a new process finds them (all zero): the reset()/match() sequence API otherwise keeps, like
+        the reference, what earlier frames of other shapes left in the words census_transform_5x5 never writes (Q3)."""
+        self.lib.sgmo_clear_census(self.ctx)
+
     def run(self, left, right, opt):
-        """Reset + Match; returns the dict of all nine stages."""
+        """One frame as a fresh process computes it: clear the census statics, Reset + Match; returns the dict of all nine stages."""
         h, w = left.shape
+        self.clear_census()
         assert self.reset(w, h, opt)
         assert self.match(np.ascontiguousarray(left), np.ascontiguousarray(right)) is not None
         return self.stages()
@@ -332,11 +339,16 @@ class Reference:
     def oob_count(self):
         return int(self.lib.ref_oob_count())
 
-    def api_match(self, left, right, opt, reset=True):
-        """Through the reference's public entry points only (what bench's cpu_baseline times)."""
+    def clear_census(self):
+        self.lib.ref_clear_census()
+
+    def api_match(self, left, right, opt, reset=True, clear=True):
+        """Through the reference's public entry points only (what bench's cpu_baseline times).  clear=False leaves the reference's
+        static census buffers as the calls before left them (the raw call sequence of a long-running process, Q3)."""
         h, w = left.shape
         if reset:
-            self.lib.ref_clear_census()     # Q3: stale border values from an earlier shape
+            if clear:
+                self.lib.ref_clear_census()     # Q3: stale border values from an earlier shape
             if not self.lib.SGM_Reset(w, h, C.byref(opt)):
                 return None
         out = np.empty((h, w), np.float32)

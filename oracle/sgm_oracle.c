@@ -18,7 +18,15 @@
 
 void sgmo_census5x5(const uint8_t* img, int W, int H, uint32_t* census)
 {
-    memset(census, 0, (size_t)W * H * sizeof(uint32_t));      /* Q3: border stays 0 */
+    memset(census, 0, (size_t)W * H * sizeof(uint32_t));      /* Q3: border stays 0 (a fresh, zero-initialised buffer) */
+    sgmo_census5x5_interior(img, W, H, census);
+}
+
+/* Exactly the stores of ref :134-159: interior pixels only.  The 2-pixel border -- and, for W <= 5 or H <= 5, every pixel
+ * (ref :136) -- is left as it is: in the reference the buffer is a static array (SemiGlobalMatching.h:67-68) that is never
+ * cleared, so those words keep what an earlier frame, possibly of another shape, left at the same linear index. */
+void sgmo_census5x5_interior(const uint8_t* img, int W, int H, uint32_t* census)
+{
     if (W <= 5 || H <= 5) return;                             /* ref :136 */
     for (int y = 2; y < H - 2; ++y) {
         for (int x = 2; x < W - 2; ++x) {
@@ -416,7 +424,10 @@ struct sgmo_ctx {
     int reference_view;       /* 0 = left (reference), 1 = right (extension) */
     uint64_t *census64_l, *census64_r;
     bool ready;
+    /* ref .h:67-68: the census buffers are statics that outlive SGM_Reset; modelled as two buffers that only ever grow
+     * (zero-extended, contents kept at their linear indices) and that sgmo_match writes in the interior only */
     uint32_t *census_l, *census_r;
+    size_t census_px;
     uint8_t* cost;
     uint16_t* aggr;
     float* stage_f[5];      /* dispL after WTA, dispR, after LR, after speckle, final */
@@ -427,18 +438,40 @@ sgmo_ctx* sgmo_create(void) { return (sgmo_ctx*)calloc(1, sizeof(sgmo_ctx)); }
 
 static void release_buffers(sgmo_ctx* c)
 {
-    free(c->census_l); free(c->census_r); free(c->cost); free(c->aggr);
+    free(c->cost); free(c->aggr);
     free(c->census64_l); free(c->census64_r);
     c->census64_l = c->census64_r = NULL;
     for (int i = 0; i < 5; ++i) free(c->stage_f[i]);
-    c->census_l = c->census_r = NULL; c->cost = NULL; c->aggr = NULL;
+    c->cost = NULL; c->aggr = NULL;
     memset(c->stage_f, 0, sizeof c->stage_f);
+}
+
+static bool grow_census(sgmo_ctx* c, size_t px)
+{
+    if (px <= c->census_px) return true;
+    uint32_t* l = (uint32_t*)realloc(c->census_l, px * sizeof(uint32_t));
+    if (l) c->census_l = l;
+    uint32_t* r = (uint32_t*)realloc(c->census_r, px * sizeof(uint32_t));
+    if (r) c->census_r = r;
+    if (!l || !r) return false;
+    memset(c->census_l + c->census_px, 0, (px - c->census_px) * sizeof(uint32_t));
+    memset(c->census_r + c->census_px, 0, (px - c->census_px) * sizeof(uint32_t));
+    c->census_px = px;
+    return true;
+}
+
+/* the reference's statics as a new process finds them (what oracle/ref_harness_tail.c's ref_clear_census does to the reference) */
+void sgmo_clear_census(sgmo_ctx* c)
+{
+    if (c->census_l) memset(c->census_l, 0, c->census_px * sizeof(uint32_t));
+    if (c->census_r) memset(c->census_r, 0, c->census_px * sizeof(uint32_t));
 }
 
 void sgmo_destroy(sgmo_ctx* c)
 {
     if (!c) return;
     release_buffers(c);
+    free(c->census_l); free(c->census_r);
     free(c);
 }
 
@@ -464,13 +497,12 @@ bool sgmo_initialize(sgmo_ctx* c, uint16_t width, uint16_t height, const sgmo_op
     if (c->W != width || c->H != height || c->D != D || !c->aggr) {
         release_buffers(c);
         const size_t px = (size_t)width * height;
-        c->census_l = (uint32_t*)calloc(px, sizeof(uint32_t));
-        c->census_r = (uint32_t*)calloc(px, sizeof(uint32_t));
         c->cost = (uint8_t*)malloc(px * D);
         c->aggr = (uint16_t*)malloc(px * D * sizeof(uint16_t));
         for (int i = 0; i < 5; ++i) c->stage_f[i] = (float*)calloc(px, sizeof(float));
     }
     c->W = width; c->H = height; c->D = D;
+    if (!grow_census(c, (size_t)width * height)) return false;
     memset(c->aggr, 0, (size_t)width * height * D * sizeof(uint16_t));   /* ref :57, Q14 */
     c->ready = c->census_l && c->census_r && c->cost && c->aggr && c->stage_f[4];
     return c->ready;
@@ -490,8 +522,8 @@ bool sgmo_match(sgmo_ctx* c, const uint8_t* left, const uint8_t* right, float* o
     const size_t px = (size_t)W * H;
 
     if (c->census_w == 0) {
-        sgmo_census5x5(left, W, H, c->census_l);
-        sgmo_census5x5(right, W, H, c->census_r);
+        sgmo_census5x5_interior(left, W, H, c->census_l);     /* ref :82-83 on the never-cleared statics (Q3) */
+        sgmo_census5x5_interior(right, W, H, c->census_r);
         sgmo_cost(c->census_l, c->census_r, W, H, o->min_disparity, o->max_disparity, c->cost);
     } else {
         if (!c->census64_l) {

@@ -47,7 +47,8 @@ typedef struct {
 /* ---- individual stages (each cites the reference lines it restates) ---- */
 
 /* SemiGlobalMatching.c:134-159.  Border (2 px) is written as 0 (Q3). */
-void sgmo_census5x5(const uint8_t* img, int W, int H, uint32_t* census);
+void sgmo_census5x5(const uint8_t* img, int W, int H, uint32_t* census);            /* into a zeroed buffer: border 0 */
+void sgmo_census5x5_interior(const uint8_t* img, int W, int H, uint32_t* census);   /* the stores of ref :134-159 only */
 
 /* Extension, pinned by this restatement only: the census transform for any odd window cw x ch of at most 64 pixels
  * (u64 words; equals sgmo_census5x5 for 5x5) and its Hamming cost. */
@@ -115,6 +116,11 @@ void      sgmo_set_reference_view(sgmo_ctx* c, int right);
 bool      sgmo_initialize(sgmo_ctx* c, uint16_t width, uint16_t height, const sgmo_option* opt);
 bool      sgmo_reset(sgmo_ctx* c, uint16_t width, uint16_t height, const sgmo_option* opt);
 bool      sgmo_match(sgmo_ctx* c, const uint8_t* left, const uint8_t* right, float* disp_left);
+/* The context's census buffers behave like the reference's statics (SemiGlobalMatching.h:67-68): zero when the
+ * context is created, never cleared by sgmo_reset, written by sgmo_match in the interior only -- so after a Reset to another
+ * shape the 2-pixel border (every pixel for W <= 5 or H <= 5) holds what earlier frames left at the same linear index, exactly
+ * as a sequence of SGM_Reset / SGM_Match calls on the reference does.  sgmo_clear_census = a new process. */
+void      sgmo_clear_census(sgmo_ctx* c);
 
 /* Stage buffers of the last sgmo_match (valid until the next call / destroy).
  * which: 0 censusL(u32) 1 censusR(u32) 2 cost(u8) 3 aggr(u16) 4 dispL after WTA(f32)

@@ -9,7 +9,6 @@ has no CPU fallback -- importing works anywhere, calling into the library needs 
 from .sgm import (SGM, SGMInstance, SGMOption, default_option, library_path, load_library,  # noqa: F401
                   STAGE_NAMES, synth_pair)
 from .sharding import SGMStream, frames_of_rank, match_sharded  # noqa: F401
-from .platform import board_gray, compare_depth, disparity_to_depth  # noqa: F401
 
 __all__ = ["SGM", "SGMInstance", "SGMOption", "default_option", "library_path", "load_library", "STAGE_NAMES",
            "synth_pair", "SGMStream", "frames_of_rank", "match_sharded"]

@@ -66,13 +66,19 @@ int sgmd_aggregate(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* 
     return aggregate_any(ord, stream, g, paths, img_left, census_l, census_r, nullptr, lut, planes, plane_bytes, extras);
 }
 
-/* diagnostics: shader-clock ticks and 100 MHz ticks over the lifetime of block 0 of the last aggregation launch (this TU's kernels) */
+/* diagnostics (builds with -DSGM_CLOCK_PROBE only; -1 otherwise): shader-clock ticks and 100 MHz ticks over the lifetime of
+ * block 0 of the last aggregation launch of this translation unit's kernels */
 int sgmd_debug_clock(int ord, unsigned long long out[2])
 {
+#ifdef SGM_CLOCK_PROBE
     HIP_TRY(hipSetDevice(ord));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sgm_agg_clock), 2 * sizeof(unsigned long long)));
     return 0;
+#else
+    (void)ord; out[0] = out[1] = 0;
+    return -1;
+#endif
 }
 
 int sgmd_aggregate_volume(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* paths, const void* img_left,

@@ -595,14 +595,18 @@ static __device__ __forceinline__ void agg_anomalous(const AggArgs& a, const Agg
 
 // NN: the step for non-negative P1 (agg_step_nn); the generic step only serves negative P1, for which the host
 // keeps to 16 lanes per pixel everywhere (sgm_host.c), so only those combinations are instantiated without NN
-// Diagnostics: the shader clock the launch runs at -- s_memtime (shader-clock ticks) against s_memrealtime (100 MHz) over the
-// lifetime of one long-running wave (block 0 = horizontal lines of frame 0: W-1 steps); read back with sgmd_debug_clock().
-// Two scalar loads per wave, nothing in the loops.
-__device__ unsigned long long g_sgm_agg_clock[2];
+// Diagnostics, compiled in only with -DSGM_CLOCK_PROBE (make CLOCK_PROBE=1; tools/agg_clock.py builds such a variant): the shader
+// clock the launch runs at -- s_memtime (shader-clock ticks) against s_memrealtime (100 MHz) over the lifetime of one long-running
+// wave (block 0 = horizontal lines of frame 0: W-1 steps); read back with sgmd_debug_clock(), which covers the kernels of
+// sgm_aggregate.hip (the symbol is per translation unit).  The default build has no diagnostic loads or stores in the kernel.
+#ifdef SGM_CLOCK_PROBE
+static __device__ unsigned long long g_sgm_agg_clock[2];
+#endif
 
 template <int DPL, bool PAD, int LPP, int HL, bool NN, bool VOL = false>
 __global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
 {
+#ifdef SGM_CLOCK_PROBE
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
     struct ClockProbe {
         unsigned long long c0, r0;
@@ -613,6 +617,7 @@ __global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
             }
         }
     } probe{clk0, rt0};
+#endif
     __shared__ unsigned short lut_s[256];
     __shared__ unsigned lut32_s[256];                        // the same penalties in both halves of a dword (packed u16 operand)
     const int lane = threadIdx.x;

@@ -13,7 +13,7 @@
 // need (row tiles): one byte per 64 x 16 block of the image, 0 = nobody on this GPU reads the block's census words
 __global__ __launch_bounds__(256) void sgm_census_k(const uint8_t* __restrict__ left, const uint8_t* __restrict__ right,
                                                     uint32_t* __restrict__ cl, uint32_t* __restrict__ cr, int W, int H,
-                                                    const uint8_t* __restrict__ need)
+                                                    const uint8_t* __restrict__ need, int keep_border)
 {
     if (need && !need[blockIdx.y * gridDim.x + blockIdx.x]) return;
     __shared__ uint8_t tile[(CEN_BH + 4) * CEN_LD];
@@ -37,14 +37,17 @@ __global__ __launch_bounds__(256) void sgm_census_k(const uint8_t* __restrict__ 
 #pragma unroll
         for (int c = 0; c < 5; ++c) v[r][c] = tile[(rg * 4 + r) * CEN_LD + cx + c];
     // border of 2 px is never written by the reference (zero-initialised statics, Q3); also nothing
-    // at all is written for images with W <= 5 or H <= 5 (ref :136)
+    // at all is written for images with W <= 5 or H <= 5 (ref :136).  keep_border: exactly that -- those words keep what an
+    // earlier frame (of another shape) left at the same linear index; otherwise they are written as 0
     const bool col_ok = W > 5 && H > 5 && x >= 2 && x < W - 2;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int y = y0 + rg * 4 + i;
         if (y >= H) break;
         uint32_t bits = 0;
-        if (col_ok && y >= 2 && y < H - 2) {
+        const bool interior = col_ok && y >= 2 && y < H - 2;
+        if (!interior && keep_border) continue;
+        if (interior) {
             const unsigned centre = v[i + 2][2];
 #pragma unroll
             for (int r = 0; r < 5; ++r)
@@ -187,12 +190,13 @@ void sgmd_census_blocks(const sgmd_geom* g, int* blocks_x, int* blocks_y)
     *blocks_y = (g->H + CEN_BH - 1) / CEN_BH;
 }
 
-int sgmd_census(int ord, void* stream, const sgmd_geom* g, const void* left, const void* right, void* cl, void* cr, const void* need)
+int sgmd_census(int ord, void* stream, const sgmd_geom* g, const void* left, const void* right, void* cl, void* cr, const void* need,
+                int keep_border)
 {
     HIP_TRY(hipSetDevice(ord));
     dim3 grid((g->W + CEN_BW - 1) / CEN_BW, (g->H + CEN_BH - 1) / CEN_BH, 2 * g->B);
     hipLaunchKernelGGL(sgm_census_k, grid, dim3(256), 0, (hipStream_t)stream, (const uint8_t*)left,
-                       (const uint8_t*)right, (uint32_t*)cl, (uint32_t*)cr, g->W, g->H, (const uint8_t*)need);
+                       (const uint8_t*)right, (uint32_t*)cl, (uint32_t*)cr, g->W, g->H, (const uint8_t*)need, keep_border);
     HIP_TRY(hipGetLastError());
     return 0;
 }

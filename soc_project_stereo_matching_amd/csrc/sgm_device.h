@@ -18,6 +18,10 @@ extern "C" {
 int   sgmd_device_count(void);                       /* <= 0: no usable device */
 int   sgmd_device_is_gfx950(int ordinal);            /* 1 yes, 0 no, <0 error */
 int   sgmd_stream_create(int ordinal, void** stream);
+/* a stream whose kernels run only on compute units [first, first + count) of EVERY XCD (hipExtStreamCreateWithCUMask; the mask's
+ * bit i is CU i / xcds of XCD i % xcds).  count <= 0: an ordinary stream on all CUs */
+int   sgmd_stream_create_cus(int ordinal, void** stream, int first_per_xcd, int count_per_xcd);
+int   sgmd_device_cus(int ordinal, int* cus_per_xcd, int* xcds);     /* 32 x 8 on MI355X */
 int   sgmd_stream_destroy(int ordinal, void* stream);
 int   sgmd_stream_sync(int ordinal, void* stream);
 /* events without timing, for ordering one stream behind another */
@@ -82,8 +86,11 @@ typedef struct {
 /* 5x5 census of both images; border = 0.  SemiGlobalMatching.c:134-159 */
 /* need: NULL, or one byte per block of the sgmd_census_blocks grid (row-major): 0 = leave the block's words as they are (a
  * row-tile instance only needs its own rows and the pixels the four anomalous lines read) */
+/* keep_border != 0: the words the reference never writes (the 2-pixel border; everything when W <= 5 or H <= 5, .c:136,140-141)
+ * are left as they are instead of being written as 0 -- the reference's static buffers keep what an earlier frame of another
+ * shape left at the same linear index */
 int sgmd_census(int ord, void* stream, const sgmd_geom* g, const void* left, const void* right,
-                void* census_l, void* census_r, const void* need);
+                void* census_l, void* census_r, const void* need, int keep_border);
 void sgmd_census_blocks(const sgmd_geom* g, int* blocks_x, int* blocks_y);     /* blocks of 64 x 16 pixels */
 
 /* Hamming matching cost volume, u8 [H][W][Dp].  SemiGlobalMatching.c:161-196 */
@@ -143,8 +150,10 @@ int sgmd_speckle(int ord, void* stream, const sgmd_geom* g, void* disp, float di
 
 /* in-place raster-order 3x3 median (the reference calls MedianFilter with in == out, .c:120).
  * scratch: sgmd_median_scratch_bytes(g) bytes for the pre-sorted neighbourhoods. */
+/* status: NULL, or an int in page-locked host memory (sgmd_alloc_pinned) that the chained kernel of tall frames sets to 1 when a
+ * band gave up waiting for the rows of the band above (bounded polls): the map is then wrong and the host fails the match */
 size_t sgmd_median_scratch_bytes(const sgmd_geom* g);
-int sgmd_median(int ord, void* stream, const sgmd_geom* g, void* disp, void* scratch);
+int sgmd_median(int ord, void* stream, const sgmd_geom* g, void* disp, void* scratch, void* status);
 
 /* SURVEY.md 8f-3 on device buffers: depth[mm] = float32(fx * baseline) / (disparity + doffs), NaN where the denominator is not
  * finite or zero; and (blocking) the sums behind RMSE / bad-pixel rate over the pixels finite in both depth images */

@@ -31,17 +31,26 @@ static const int k_dir_dy[8] = {0, 0, 1, -1, 1, -1, -1, 1};
 
 struct sgm_instance {
     int device;
-    void* stream;
-    void* post_stream;           /* sgm_set_overlap_post: LR check, speckle removal and median of a match run here ... */
-    void *ev_sum, *ev_post;      /* ... behind ev_sum (cost sum + WTAs done); ev_post = that post pass done */
+    void* stream;                /* census and aggregation; and every other stage unless it has a stream of its own (sgm_set_stage_cus) */
+    void* sum_stream;            /* cost sum + both WTAs, behind ev_agg (the aggregation is done) */
+    void* post_stream;           /* LR check, speckle removal and median, behind ev_sum (cost sum + WTAs done); ev_post = post pass done */
+    void *ev_agg, *ev_sum, *ev_post;
     int overlap_post;
+    bool sum_pending;            /* a cost sum is (possibly) still reading the planes on sum_stream */
     bool post_pending;           /* a post pass is (possibly) still running on post_stream */
+    void* tail_stream;           /* the stream the last match's final kernel was queued on (NULL: stream) */
+    int cu_first[3], cu_count[3];/* CUs per XCD of the main / sum / post stream (count 0: all CUs) */
+    int* h_status;               /* page-locked word the chained median kernel sets when a band gave up waiting (sgmd_median) */
     void* timer;
     int timing;
     int keep_stages;
     int honor_num_paths;
     int census_w, census_h;      /* census window (sgm_set_census_window); 0 = the reference's 5x5 */
     int reference_view;          /* 0 = left (reference), 1 = right (sgm_set_reference_view) */
+    int reference_statics;       /* the default instance behind SGM_Initialize / SGM_Reset / SGM_Match: its census buffers behave like
+                                    the reference's static arrays (SemiGlobalMatching.h:67-68) -- zero at first, never cleared, the words
+                                    census_transform_5x5 does not write (.c:136,140-141) keep what an earlier frame of another shape left
+                                    at the same linear index.  Explicit instances (an extension) write those words as 0 */
     int batch;                   /* frames per match call (>= 1); takes effect at the next initialize */
     int read_frame;              /* which frame of the batch sgm_read_stage returns */
     int tile_begin, tile_end;    /* row tile this instance computes (sgm_set_rows); tile_end == 0: the whole frame */
@@ -104,8 +113,14 @@ struct sgm_instance {
 static int sync_streams(sgm_instance* s)
 {
     int rc = sgmd_stream_sync(s->device, s->stream);
+    if (s->sum_stream && sgmd_stream_sync(s->device, s->sum_stream) != 0) rc = -1;
     if (s->post_stream && sgmd_stream_sync(s->device, s->post_stream) != 0) rc = -1;
-    if (rc == 0) s->post_pending = false;
+    if (rc == 0) { s->post_pending = s->sum_pending = false; s->tail_stream = NULL; }
+    if (rc == 0 && s->h_status && *s->h_status) {
+        *s->h_status = 0;
+        fprintf(stderr, "sgm_mi355x: the median of a tall frame gave up waiting for the band above; the result is not valid\n");
+        rc = -1;
+    }
     return rc;
 }
 
@@ -190,6 +205,10 @@ sgm_instance* sgm_create(int device)
     s->device = device;
     s->batch = 1;
     if (sgmd_stream_create(device, &s->stream) != 0) { free(s); return NULL; }
+    void* st = NULL;
+    if (sgmd_alloc_pinned(device, &st, 64) != 0) { sgmd_stream_destroy(device, s->stream); free(s); return NULL; }
+    s->h_status = (int*)st;
+    *s->h_status = 0;
     return s;
 }
 
@@ -224,24 +243,62 @@ void sgm_destroy(sgm_instance* s)
     sync_streams(s);
     free_device_buffers(s);
     sgmd_timer_destroy(s->device, s->timer);
+    sgmd_event_destroy(s->device, s->ev_agg);
     sgmd_event_destroy(s->device, s->ev_sum);
     sgmd_event_destroy(s->device, s->ev_post);
+    if (s->sum_stream) sgmd_stream_destroy(s->device, s->sum_stream);
     if (s->post_stream) sgmd_stream_destroy(s->device, s->post_stream);
     sgmd_stream_destroy(s->device, s->stream);
+    sgmd_free_pinned(s->device, s->h_status);
     free(s);
 }
 
 void sgm_set_honor_num_paths(sgm_instance* s, int honor) { if (s) s->honor_num_paths = honor; }
 
+/* the three ordering events exist as soon as any stage has a stream of its own; all or none */
+static bool ensure_stage_events(sgm_instance* s)
+{
+    void** ev[3] = {&s->ev_agg, &s->ev_sum, &s->ev_post};
+    for (int i = 0; i < 3; ++i)
+        if (!*ev[i] && sgmd_event_create(s->device, ev[i]) != 0) { *ev[i] = NULL; return false; }
+    return true;
+}
+
+/* Stage groups on streams of their own, optionally on their own compute units (include/sgm_mi355x.h).  The instance is idle
+ * while its streams change. */
+bool sgm_set_stage_cus(sgm_instance* s, int which, int first_per_xcd, int count_per_xcd)
+{
+    if (!s || which < SGM_STAGE_MAIN || which > SGM_STAGE_POST) return false;
+    if (!sgm_match_wait(s) || sync_streams(s) != 0) return false;
+    void** slot = which == SGM_STAGE_MAIN ? &s->stream : (which == SGM_STAGE_SUM ? &s->sum_stream : &s->post_stream);
+    if (count_per_xcd < 0) {                                     /* back to the default */
+        if (which == SGM_STAGE_MAIN) return sgm_set_stage_cus(s, which, 0, 0);
+        if (*slot) sgmd_stream_destroy(s->device, *slot);
+        *slot = NULL;
+        if (which == SGM_STAGE_POST) s->overlap_post = 0;
+        s->cu_first[which] = s->cu_count[which] = 0;
+        return true;
+    }
+    if (*slot && s->cu_first[which] == first_per_xcd && s->cu_count[which] == count_per_xcd) {
+        if (which == SGM_STAGE_POST) s->overlap_post = 1;
+        return true;
+    }
+    void* fresh = NULL;
+    if (!ensure_stage_events(s) || sgmd_stream_create_cus(s->device, &fresh, first_per_xcd, count_per_xcd) != 0) return false;
+    if (*slot) sgmd_stream_destroy(s->device, *slot);
+    *slot = fresh;
+    s->cu_first[which] = first_per_xcd;
+    s->cu_count[which] = count_per_xcd;
+    if (which == SGM_STAGE_POST) s->overlap_post = 1;
+    return true;
+}
+
 bool sgm_set_overlap_post(sgm_instance* s, int enable)
 {
     if (!s) return false;
-    if (enable && !s->post_stream) {
-        if (sgmd_stream_create(s->device, &s->post_stream) != 0) { s->post_stream = NULL; return false; }
-        if (sgmd_event_create(s->device, &s->ev_sum) != 0 || sgmd_event_create(s->device, &s->ev_post) != 0) return false;
-    }
-    if (!enable && s->overlap_post) sync_streams(s);             /* the next match is ordered on sgm_stream alone again */
-    s->overlap_post = enable ? 1 : 0;
+    if (enable) return s->post_stream ? (s->overlap_post = 1, true) : sgm_set_stage_cus(s, SGM_STAGE_POST, 0, 0);
+    if (s->overlap_post) sync_streams(s);                        /* the next match is ordered on sgm_stream alone again */
+    s->overlap_post = 0;
     return true;
 }
 
@@ -421,6 +478,10 @@ static bool ensure_buffers(sgm_instance* s)
     int rc = 0;
     if (px > s->cap_px || !s->d_disp) {
         sync_streams(s);
+        /* the census words of earlier frames outlive a re-allocation (reference_statics): set the old buffers aside */
+        void *old_l = s->d_census_l, *old_r_alloc = s->d_census_r_alloc;
+        const size_t old_px = s->cap_px;
+        s->d_census_l = s->d_census_r_alloc = NULL;
         free_device_buffers(s);
         rc |= sgmd_alloc(dev, &s->d_left, px);
         rc |= sgmd_alloc(dev, &s->d_right, px);
@@ -429,6 +490,16 @@ static bool ensure_buffers(sgm_instance* s)
          * afterwards); give the buffer that much readable slack in front, sized for the largest options */
         rc |= sgmd_alloc(dev, &s->d_census_r_alloc, CENSUS_FRONT_SLACK + px * 4);
         if (rc == 0) s->d_census_r = (char*)s->d_census_r_alloc + CENSUS_FRONT_SLACK;
+        /* zero like the reference's statics; then the words earlier frames left, at their linear indices */
+        if (rc == 0) rc |= sgmd_memset_async(dev, s->stream, s->d_census_l, 0, px * 4);
+        if (rc == 0) rc |= sgmd_memset_async(dev, s->stream, s->d_census_r_alloc, 0, CENSUS_FRONT_SLACK + px * 4);
+        if (rc == 0 && s->reference_statics && old_l && old_r_alloc && old_px) {
+            rc |= sgmd_d2d_async(dev, s->stream, s->d_census_l, old_l, old_px * 4);
+            rc |= sgmd_d2d_async(dev, s->stream, s->d_census_r, (char*)old_r_alloc + CENSUS_FRONT_SLACK, old_px * 4);
+        }
+        if (rc == 0) rc |= sgmd_stream_sync(dev, s->stream);
+        sgmd_free(dev, old_l);
+        sgmd_free(dev, old_r_alloc);
         rc |= sgmd_alloc(dev, &s->d_disp, px * 4);
         rc |= sgmd_alloc(dev, &s->d_disp_r, px * 4);
         rc |= sgmd_alloc(dev, &s->d_labels, px * 4);
@@ -476,6 +547,7 @@ static int ensure_S(sgm_instance* s)
     s->cap_S = 0;
     int rc = sgmd_alloc(s->device, &s->d_S, need);
     if (rc == 0) rc = sgmd_memset_async(s->device, s->stream, s->d_S, 0, need);
+    if (rc == 0 && s->sum_stream) rc = sgmd_stream_sync(s->device, s->stream);   /* the cost sum may run on another stream */
     if (rc == 0) s->cap_S = need;
     else fprintf(stderr, "sgm_mi355x: device allocation failed for the aggregated-cost volume (%zu bytes)\n", need);
     return rc;
@@ -624,7 +696,9 @@ static int materialize_S(sgm_instance* s)
 {
     if (!s->s_pending) return 0;
     if (ensure_S(s) != 0) return -1;
-    /* the scratch map below is the speckle pass's label map: a post pass still running on its own stream comes first */
+    /* d_S may still be in use by a cost sum on its own stream; the scratch map below is the speckle pass's label map: a post
+     * pass still running on its own stream comes first */
+    if (s->sum_pending && sgmd_stream_wait_event(s->device, s->stream, s->ev_sum) != 0) return -1;
     if (s->post_pending && sgmd_stream_wait_event(s->device, s->stream, s->ev_post) != 0) return -1;
     /* the left-view WTA this kernel also produces goes to a dead scratch map (speckle labels) */
     const int rc = sgmd_sum_wta(s->device, s->stream, &s->g, s->paths.ndirs, s->d_planes, s->plane_bytes, s->d_extras,
@@ -636,7 +710,7 @@ static int materialize_S(sgm_instance* s)
 
 /* .c:94 (sum over the directions), .c:99 and .c:105 (both ComputeDisparity calls).  The Q14 bookkeeping (s_is_zero,
  * s_pending) changes only when every launch of the stage was accepted. */
-static int sum_and_wta(sgm_instance* s, void* d_out, bool with_marks)
+static int sum_and_wta(sgm_instance* s, void* st, void* d_out, bool with_marks)
 {
     const SGMOption* o = &s->opt;
     const int accumulate = s->s_is_zero ? 0 : 1;                 /* Q14 */
@@ -646,22 +720,22 @@ static int sum_and_wta(sgm_instance* s, void* d_out, bool with_marks)
     if ((!s->fused_wta || accumulate || s->keep_stages) && ensure_S(s) != 0) return -1;
     if (s->fused_wta) {
         const int store = s->keep_stages ? 1 : 0;
-        rc = sgmd_sum_wta_lr(s->device, s->stream, &s->g, s->paths.ndirs, s->d_planes, s->plane_bytes, s->d_extras,
+        rc = sgmd_sum_wta_lr(s->device, st, &s->g, s->paths.ndirs, s->d_planes, s->plane_bytes, s->d_extras,
                              s->d_row_extras, s->d_row_count, s->row_cap, accumulate, store, (o->is_check_lr || s->reference_view) ? 1 : 0, s->d_S,
                              uniq, keep, d_out, s->d_disp_r);
         if (rc != 0) return rc;
         s->s_pending = !store;
         s->s_pending_accumulate = accumulate != 0;
-        if (with_marks) mark(s, 4);
+        if (with_marks) mark_on(s, st, 4);
     } else {
-        rc = sgmd_sum_wta(s->device, s->stream, &s->g, s->paths.ndirs, s->d_planes, s->plane_bytes, s->d_extras,
+        rc = sgmd_sum_wta(s->device, st, &s->g, s->paths.ndirs, s->d_planes, s->plane_bytes, s->d_extras,
                           s->d_row_extras, s->d_row_count, s->row_cap, accumulate, s->d_S, uniq, keep, d_out);
         if (rc != 0) return rc;
         /* d_S now holds this frame's sum whatever happens next */
         s->s_pending = false;
         s->s_is_zero = false;
-        if (with_marks) mark(s, 4);
-        if (o->is_check_lr || s->reference_view) rc = sgmd_wta_right(s->device, s->stream, &s->g, s->d_S, uniq, keep, s->d_disp_r);
+        if (with_marks) mark_on(s, st, 4);
+        if (o->is_check_lr || s->reference_view) rc = sgmd_wta_right(s->device, st, &s->g, s->d_S, uniq, keep, s->d_disp_r);
         if (rc != 0) return rc;
     }
     s->s_is_zero = false;
@@ -678,7 +752,10 @@ static int prepare_costs(sgm_instance* s, const void* d_left, const void* d_righ
             if (sgmd_memset_async(s->device, s->stream, s->d_census_l, 0xA5, bytes) != 0 ||
                 sgmd_memset_async(s->device, s->stream, s->d_census_r, 0x5A, bytes) != 0) return -1;
         }
-        return sgmd_census(s->device, s->stream, &s->g, d_left, d_right, s->d_census_l, s->d_census_r, tiled ? s->d_census_need : NULL);
+        /* the reference's own boundary, one whole frame per match: the unwritten census words stay as they are (Q3) */
+        const int keep_border = s->reference_statics && s->g.B == 1 && s->tile_end == 0;
+        return sgmd_census(s->device, s->stream, &s->g, d_left, d_right, s->d_census_l, s->d_census_r, tiled ? s->d_census_need : NULL,
+                           keep_border);
     }
     const size_t need = (size_t)s->g.B * s->g.W * s->g.H * 8;
     if (need > s->cap_census64 || !s->d_census64_l) {
@@ -737,6 +814,12 @@ static bool run_pipeline(sgm_instance* s, const void* d_left, const void* d_righ
     const SGMOption* o = &s->opt;
     const size_t px_bytes = (size_t)g->B * g->W * g->H * sizeof(float);
 
+    /* stage groups on streams of their own (sgm_set_stage_cus / sgm_set_overlap_post; never in row-tile mode) */
+    const bool own_sum = s->sum_stream && s->tile_end == 0;
+    const bool overlap = s->overlap_post && s->post_stream && s->tile_end == 0;
+    void *sts = st, *st2 = st;
+    /* the aggregation rewrites the planes the previous match's cost sum may still be reading on its own stream */
+    if (s->sum_pending) LAUNCH(sgmd_stream_wait_event(dev, st, s->ev_sum));
     if (!s->s_is_zero) LAUNCH(materialize_S(s));             /* Match without Reset: S of the previous frame is needed now */
     mark(s, 0);
     LAUNCH(prepare_costs(s, d_left, d_right));                                                      /* .c:82-83 */
@@ -753,19 +836,24 @@ static bool run_pipeline(sgm_instance* s, const void* d_left, const void* d_righ
             LAUNCH(sgmd_memset_async(dev, st, (char*)s->d_planes_alloc + ((size_t)f * 8 + 4) * s->plane_bytes, 0, 4 * s->plane_bytes));
     LAUNCH(launch_aggregation(s, &s->paths, d_left));                                               /* .c:94 */
     mark(s, 3);
+    if (own_sum) {
+        LAUNCH(sgmd_event_record(dev, s->ev_agg, st));
+        LAUNCH(sgmd_stream_wait_event(dev, s->sum_stream, s->ev_agg));
+        sts = st2 = s->sum_stream;
+    }
     /* the cost sum writes d_out and the right-view map, which the previous match's post pass may still be reading */
-    const bool overlap = s->overlap_post && s->post_stream && s->tile_end == 0;
-    if (s->post_pending) LAUNCH(sgmd_stream_wait_event(dev, st, s->ev_post));
-    LAUNCH(sum_and_wta(s, d_out, true));                                                            /* .c:94 sum, .c:99, .c:105 */
-    if (s->keep_stages) LAUNCH(sgmd_d2d_async(dev, st, s->d_snap_wta, d_out, px_bytes));
-    mark(s, 5);
-    /* sgm_set_overlap_post: the post pass (latency-bound kernels that fill a fraction of the GPU) moves to its own stream,
-     * so that this stream can start the next match's census and aggregation beside it */
-    void* st2 = st;
+    if (s->post_pending) LAUNCH(sgmd_stream_wait_event(dev, sts, s->ev_post));
+    LAUNCH(sum_and_wta(s, sts, d_out, true));                                                       /* .c:94 sum, .c:99, .c:105 */
+    if (s->keep_stages) LAUNCH(sgmd_d2d_async(dev, sts, s->d_snap_wta, d_out, px_bytes));
+    mark_on(s, sts, 5);
+    /* the post pass (latency-bound kernels that fill a fraction of the GPU) on its own stream, so that the stream(s) before it
+     * can start the next match's census, aggregation and cost sum beside it */
+    if (overlap || own_sum) LAUNCH(sgmd_event_record(dev, s->ev_sum, sts));
+    if (own_sum) s->sum_pending = true;
     if (overlap) {
-        LAUNCH(sgmd_event_record(dev, s->ev_sum, st));
         LAUNCH(sgmd_stream_wait_event(dev, s->post_stream, s->ev_sum));
         st2 = s->post_stream;
+        s->post_pending = true;                                  /* from here on the post stream has work of this match */
     }
     LAUNCH(lr_stage(s, st2, d_out));                                                                /* .c:109 */
     if (s->keep_stages) LAUNCH(sgmd_d2d_async(dev, st2, s->d_snap_lr, d_out, px_bytes));
@@ -774,19 +862,22 @@ static bool run_pipeline(sgm_instance* s, const void* d_left, const void* d_righ
         LAUNCH(sgmd_speckle(dev, st2, g, d_out, 1.0f, o->min_speckle_area, s->d_labels, s->d_sizes, s->d_totals));
     if (s->keep_stages) LAUNCH(sgmd_d2d_async(dev, st2, s->d_snap_speckle, d_out, px_bytes));
     mark_on(s, st2, 7);
-    LAUNCH(sgmd_median(dev, st2, g, d_out, s->d_median_scratch));                                   /* .c:120 */
+    LAUNCH(sgmd_median(dev, st2, g, d_out, s->d_median_scratch, s->h_status));                                   /* .c:120 */
     mark_on(s, st2, 8);
-    if (overlap) {
-        LAUNCH(sgmd_event_record(dev, s->ev_post, st2));
-        s->post_pending = true;
-    }
+    if (overlap) LAUNCH(sgmd_event_record(dev, s->ev_post, st2));
+    else if (own_sum) LAUNCH(sgmd_event_record(dev, s->ev_sum, st2));   /* the post pass ran on the sum stream: "sum done" = all of it */
+    s->tail_stream = st2;
     if (s->timing && s->timer) {
         s->ring_next = (s->ring_next + 1) % TIMING_RING;
         if (s->ring_pending < TIMING_RING) ++s->ring_pending;      /* older sets are overwritten */
     }
     return true;
 failed:
-    /* this match's timing set is incomplete: it is recorded over by the next match (ring_next did not advance) */
+    /* this match's timing set is incomplete: it is recorded over by the next match (ring_next did not advance).  Work may sit
+     * on the sum / post stream without the event a later match would wait for: drain everything, so that nothing of the
+     * abandoned match is still running when its buffers are reused */
+    if (s->sum_stream || s->post_stream) sync_streams(s);
+    s->tail_stream = st;
     FAIL("a kernel launch failed; the match was abandoned");
 }
 
@@ -880,7 +971,7 @@ bool sgm_tile_sweep(sgm_instance* s, int forward)
 bool sgm_tile_finish(sgm_instance* s, float* d_disp_left)
 {
     if (!s || !s->initialized || !s->tile_left || !d_disp_left) return false;
-    int rc = sum_and_wta(s, d_disp_left, false);
+    int rc = sum_and_wta(s, s->stream, d_disp_left, false);
     if (rc == 0) rc = lr_stage(s, s->stream, d_disp_left);
     s->tile_left = NULL;
     if (rc != 0) FAIL("a kernel launch failed");
@@ -894,9 +985,41 @@ bool sgm_tile_post(sgm_instance* s, float* d_disp_left)
     if (s->opt.is_remove_speckles)
         rc = sgmd_speckle(s->device, s->stream, &s->g, d_disp_left, 1.0f, s->opt.min_speckle_area, s->d_labels, s->d_sizes,
                           s->d_totals);
-    if (rc == 0) rc = sgmd_median(s->device, s->stream, &s->g, d_disp_left, s->d_median_scratch);
+    if (rc == 0) rc = sgmd_median(s->device, s->stream, &s->g, d_disp_left, s->d_median_scratch, s->h_status);
     if (rc != 0) FAIL("a kernel launch failed");
     return true;
+}
+
+/* the stream the instance's last match finishes on (the post-pass or cost-sum stream when those stages have their own) */
+static void* result_stream(sgm_instance* s) { return s->tail_stream ? s->tail_stream : s->stream; }
+
+/* the event later matches wait for before they reuse what the tail of the last match works on */
+static void* result_event(sgm_instance* s)
+{
+    void* st = result_stream(s);
+    if (st == s->stream) return NULL;                            /* stream order does it */
+    return st == s->post_stream ? s->ev_post : s->ev_sum;
+}
+
+/* more work on the result of the last match, queued behind it on the stream it finished on: re-record that stream's "done" event
+ * so that the next match's waits cover it */
+static int rerecord_result_event(sgm_instance* s)
+{
+    void* ev = result_event(s);
+    return ev ? sgmd_event_record(s->device, ev, result_stream(s)) : 0;
+}
+
+/* make `stream` wait for the last match's result */
+static int wait_for_result(sgm_instance* s, void* stream)
+{
+    void* ev = result_event(s);
+    if (!ev || stream == result_stream(s)) return 0;
+    return sgmd_stream_wait_event(s->device, stream, ev);
+}
+
+static bool queue_result_copy(sgm_instance* s, void* host_dst, const void* d_src, size_t bytes)
+{
+    return sgmd_d2h_async(s->device, result_stream(s), host_dst, d_src, bytes) == 0 && rerecord_result_event(s) == 0;
 }
 
 static void collect_timing(sgm_instance* s)
@@ -969,8 +1092,7 @@ bool sgm_match_async(sgm_instance* s, const uint8_t* img_left, const uint8_t* im
     bool ok = sgmd_h2d_async(s->device, s->stream, s->d_left, src_l, px) == 0 &&
               sgmd_h2d_async(s->device, s->stream, s->d_right, src_r, px) == 0 &&
               run_pipeline(s, s->d_left, s->d_right, s->d_disp) &&
-              sgmd_d2h_async(s->device, s->post_pending ? s->post_stream : s->stream, out_pinned ? (void*)disp_left : s->h_disp, s->d_disp,
-                             px * sizeof(float)) == 0;
+              queue_result_copy(s, out_pinned ? (void*)disp_left : s->h_disp, s->d_disp, px * sizeof(float));
     if (!ok) {
         sync_streams(s);                  /* queued copies may still read the caller's / staging buffers */
         return false;
@@ -1000,8 +1122,8 @@ bool sgm_disparity_to_depth(sgm_instance* s, const float* d_disparity, size_t co
                             float* d_depth)
 {
     if (!s || !d_disparity || !d_depth) return false;
-    /* the map may be the result of a match whose post pass runs on the second stream (sgm_set_overlap_post) */
-    if (s->post_pending && sgmd_stream_wait_event(s->device, s->stream, s->ev_post) != 0) return false;
+    /* the map may be the result of a match whose last stages run on a stream of their own (sgm_set_overlap_post / _stage_cus) */
+    if (wait_for_result(s, s->stream) != 0) return false;
     return sgmd_depth(s->device, s->stream, d_disparity, count, fx, baseline, doffs, d_depth) == 0;
 }
 
@@ -1031,9 +1153,6 @@ static int ensure_planes_io(sgm_instance* s)
     return 0;
 }
 
-/* the stream the instance's last match finishes on (the post-pass stream while sgm_set_overlap_post has work on it) */
-static void* result_stream(sgm_instance* s) { return s->post_pending ? s->post_stream : s->stream; }
-
 bool sgm_match_planes_async(sgm_instance* s, const uint8_t* planes, float fx, float baseline, float doffs, float* depth)
 {
     if (!s || !s->initialized) return false;
@@ -1056,7 +1175,7 @@ bool sgm_match_planes_async(sgm_instance* s, const uint8_t* planes, float fx, fl
     void* st = result_stream(s);
     ok = ok && sgmd_depth(dev, st, s->d_disp, px, fx, baseline, doffs, s->d_depth) == 0 &&
          sgmd_d2h_async(dev, st, out_pinned ? (void*)depth : s->h_disp, s->d_depth, px * sizeof(float)) == 0;
-    if (ok && s->post_pending) ok = sgmd_event_record(dev, s->ev_post, st) == 0;   /* the next match's cost sum waits for these too */
+    if (ok) ok = rerecord_result_event(s) == 0;                  /* the next match's cost sum waits for these too */
     if (!ok) {
         sync_streams(s);
         return false;
@@ -1078,7 +1197,7 @@ bool sgm_compare_depth(sgm_instance* s, const float* d_ground_truth, const float
     if (!s || !d_ground_truth || !d_test) return false;
     double sumsq = 0.0;
     unsigned long long n = 0, bad = 0;
-    if (s->post_pending && sgmd_stream_wait_event(s->device, s->stream, s->ev_post) != 0) return false;
+    if (wait_for_result(s, s->stream) != 0) return false;
     if (sgmd_score(s->device, s->stream, d_ground_truth, d_test, count, abs_thresh, &sumsq, &n, &bad) != 0) return false;
     if (n_valid) *n_valid = n;
     /* depth_image.py:306-308: (nan, nan, 0) when no pixel is finite in both images */
@@ -1205,6 +1324,7 @@ bool SGM_Initialize(uint16_t width, uint16_t height, const SGMOption* option)
         g_default = sgm_create(default_device());
         if (!g_default) return false;
         g_default->honor_num_paths = g_default_honor;
+        g_default->reference_statics = 1;
         if (g_default_census_w) sgm_set_census_window(g_default, g_default_census_w, g_default_census_h);
         sgm_set_reference_view(g_default, g_default_view);
     }

@@ -447,7 +447,7 @@ template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void sgm_median_chain_k(const float* __restrict__ disp, float4* __restrict__ P,
                                                                  float4* __restrict__ O, unsigned long long* __restrict__ G,
                                                                  int* __restrict__ ticket, unsigned long long* __restrict__ sink,
-                                                                 int W, int H, int Tq, unsigned gen)
+                                                                 int W, int H, int Tq, unsigned gen, int* __restrict__ status)
 {
 #undef MED_WAVES
 #define MED_WAVES WAVES
@@ -572,11 +572,15 @@ __global__ __launch_bounds__(64 * WAVES) void sgm_median_chain_k(const float* __
                     // the band above publishes its last row as granules: lanes 0..15 poll one column each
                     const int col = min(tb + 1 + (l & 15), W - 1);
                     unsigned long long gr = 0;
-                    for (int spin = 0; spin < (1 << 18); ++spin) {   // bounded: a lost producer must not hang the GPU
+                    int spin = 0;
+                    for (; spin < (1 << 18); ++spin) {               // bounded: a lost producer must not hang the GPU
                         gr = __hip_atomic_load(gin + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (__all((unsigned)(gr >> 32) == gen)) break;
                         __builtin_amdgcn_s_sleep(2);
                     }
+                    // gave up: the rows below are computed from stale values.  Tell the host (a word of pinned host memory it
+                    // reads after the next synchronisation, sgm_host.c sync_streams): the match fails instead of returning them
+                    if (spin == (1 << 18) && status && l == 0) __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     const unsigned vbits = (unsigned)gr;
 #pragma unroll
                     for (int u = 0; u < MED_PF; ++u)
@@ -814,7 +818,7 @@ size_t sgmd_median_scratch_bytes(const sgmd_geom* g)
     return (size_t)g->B * groups * med_tq(g->W) * (MED_NE + 1) * 64 * sizeof(float4) + med_granules(g, groups) * 8;
 }
 
-int sgmd_median(int ord, void* stream, const sgmd_geom* g, void* disp, void* scratch)
+int sgmd_median(int ord, void* stream, const sgmd_geom* g, void* disp, void* scratch, void* status)
 {
     HIP_TRY(hipSetDevice(ord));
     const int rows = g->H - 2;
@@ -837,7 +841,7 @@ int sgmd_median(int ord, void* stream, const sgmd_geom* g, void* disp, void* scr
         unsigned gen = __atomic_add_fetch(&generation, 1u, __ATOMIC_RELAXED);
         if (gen == 0) gen = __atomic_add_fetch(&generation, 1u, __ATOMIC_RELAXED);
         hipLaunchKernelGGL(sgm_median_chain_k<MED_CHAIN_WAVES>, dim3(nbands, g->B), dim3(64 * MED_CHAIN_WAVES), 0, st, (const float*)disp,
-                           (float4*)scratch, results, G, ticket, sink, g->W, g->H, Tq, gen);
+                           (float4*)scratch, results, G, ticket, sink, g->W, g->H, Tq, gen, (int*)status);
     } else {
         const int waves = groups < MED_WAVES ? groups : MED_WAVES;
         hipLaunchKernelGGL(sgm_median_serial_k, dim3(g->B), dim3(64 * waves), 0, st, (const float*)disp, (float4*)scratch, results,

@@ -26,6 +26,40 @@ int sgmd_stream_create(int ord, void** stream)
     *stream = (void*)s;
     return 0;
 }
+int sgmd_device_cus(int ord, int* cus_per_xcd, int* xcds)
+{
+    int cus = 0, x = 0;
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ord));
+    if (hipDeviceGetAttribute(&x, hipDeviceAttributeNumberOfXccs, ord) != hipSuccess || x <= 0) {
+        (void)hipGetLastError();
+        x = 1;
+    }
+    if (cus <= 0 || cus % x != 0) return -1;
+    *xcds = x;
+    *cus_per_xcd = cus / x;
+    return 0;
+}
+// CU mask bit i = CU (i / xcds) of XCD (i % xcds): the driver deals the bits of a queue's mask round-robin over the XCDs, so
+// "count CUs of every XCD" is one contiguous run of bits.  Every XCD keeps its own L2 and its own path to HBM in the game.
+int sgmd_stream_create_cus(int ord, void** stream, int first_per_xcd, int count_per_xcd)
+{
+    if (count_per_xcd <= 0) return sgmd_stream_create(ord, stream);
+    int per = 0, xcds = 0;
+    if (sgmd_device_cus(ord, &per, &xcds) != 0) return -1;
+    if (first_per_xcd < 0 || first_per_xcd + count_per_xcd > per) {
+        fprintf(stderr, "sgm_mi355x: CUs [%d, %d) of an XCD do not exist (%d per XCD)\n", first_per_xcd, first_per_xcd + count_per_xcd, per);
+        return -1;
+    }
+    HIP_TRY(hipSetDevice(ord));
+    uint32_t mask[32] = {0};
+    const int total = per * xcds;
+    if (total > 32 * 32) return -1;
+    for (int b = first_per_xcd * xcds; b < (first_per_xcd + count_per_xcd) * xcds; ++b) mask[b / 32] |= 1u << (b % 32);
+    hipStream_t s;
+    HIP_TRY(hipExtStreamCreateWithCUMask(&s, (uint32_t)((total + 31) / 32), mask));
+    *stream = (void*)s;
+    return 0;
+}
 int sgmd_stream_destroy(int ord, void* stream)
 {
     HIP_TRY(hipSetDevice(ord));

@@ -96,6 +96,8 @@ def load_library() -> C.CDLL:
     L.sgm_set_honor_num_paths.argtypes = [C.c_void_p, C.c_int]
     L.sgm_set_overlap_post.argtypes = [C.c_void_p, C.c_int]
     L.sgm_set_overlap_post.restype = C.c_bool
+    L.sgm_set_stage_cus.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.sgm_set_stage_cus.restype = C.c_bool
     L.sgm_set_census_window.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.sgm_set_census_window.restype = C.c_bool
     L.sgm_set_reference_view.argtypes = [C.c_void_p, C.c_int]
@@ -339,6 +341,24 @@ class SGMInstance(_StageReader):
         results are complete after synchronize(), not in order of `stream` (include/sgm_mi355x.h)."""
         return bool(self.lib.sgm_set_overlap_post(self.handle, int(enable)))
 
+    STAGE_MAIN, STAGE_SUM, STAGE_POST = 0, 1, 2
+
+    def set_stage_cus(self, which: int, first_cu_per_xcd: int = 0, cus_per_xcd: int = 0) -> bool:
+        """sgm_set_stage_cus: stage group `which` (STAGE_MAIN census + aggregation, STAGE_SUM cost sum + WTAs, STAGE_POST LR check +
+        speckle + median) on a stream of its own restricted to CUs [first, first + count) of every XCD (count 0: all CUs,
+        count < 0: back to the default)."""
+        return bool(self.lib.sgm_set_stage_cus(self.handle, which, first_cu_per_xcd, cus_per_xcd))
+
+    def set_cu_split(self, spec: str) -> bool:
+        """'post=0:2,sum=2:8,main=10:22' -> set_stage_cus per group ('first:count' CUs per XCD; 'post' alone = 'post=0:0')."""
+        which = {"main": self.STAGE_MAIN, "sum": self.STAGE_SUM, "post": self.STAGE_POST}
+        ok = True
+        for item in filter(None, (t.strip() for t in spec.split(","))):
+            name, _, rng = item.partition("=")
+            first, _, count = (rng or "0:0").partition(":")
+            ok = self.set_stage_cus(which[name], int(first or 0), int(count or 0)) and ok
+        return ok
+
     def set_census_window(self, width: int, height: int) -> bool:
         """Extension: odd census window of at most 64 pixels (5x5 = reference); next initialize/reset."""
         ok = bool(self.lib.sgm_set_census_window(self.handle, width, height))
@@ -399,12 +419,23 @@ class SGMInstance(_StageReader):
     def match_async(self, left, right, out) -> bool:
         """sgm_match_async: queue upload + pipeline + download and return.  `left`, `right` (uint8) and `out` (float32)
         must be C-contiguous arrays of the instance's shape that stay alive and untouched until match_wait()."""
+        if self.shape is None:
+            return False                                  # Match before Initialize: false in the reference (.c:70)
         for a in (left, right, out):
             if not a.flags["C_CONTIGUOUS"]:
                 raise ValueError("match_async needs C-contiguous arrays")
         if left.dtype != np.uint8 or right.dtype != np.uint8 or out.dtype != np.float32:
             raise TypeError("match_async: uint8 images, float32 output")
+        # the C side moves batch * W * H bytes (4x that for the output) whatever the arrays hold: check before handing pointers over
+        want = self._frame_shape()
+        for name, a in (("left", left), ("right", right), ("out", out)):
+            if tuple(a.shape) != want:
+                raise ValueError(f"match_async: {name} has shape {tuple(a.shape)}, the instance expects {want}")
         return bool(self.lib.sgm_match_async(self.handle, left.ctypes.data, right.ctypes.data, out.ctypes.data))
+
+    def _frame_shape(self):
+        h, w = self.shape[:2]
+        return (h, w) if self.batch == 1 else (self.batch, h, w)
 
     def match_wait(self) -> bool:
         return bool(self.lib.sgm_match_wait(self.handle))
@@ -476,6 +507,13 @@ class SGMInstance(_StageReader):
                 raise ValueError("match_planes needs C-contiguous arrays")
         if planes.dtype != np.uint8 or depth.dtype != np.float32:
             raise TypeError("match_planes: uint8 planes, float32 depth")
+        if self.shape is None:
+            return False
+        h, w = self.shape[:2]
+        if planes.size != self.batch * 6 * h * w or tuple(planes.shape[-2:]) != (h, w):
+            raise ValueError(f"match_planes: planes of shape {tuple(planes.shape)}, expected [{self.batch} x] 6 x {h} x {w}")
+        if depth.size != self.batch * h * w or tuple(depth.shape[-2:]) != (h, w):
+            raise ValueError(f"match_planes: depth of shape {tuple(depth.shape)}, expected [{self.batch} x] {h} x {w}")
         fn = self.lib.sgm_match_planes if wait else self.lib.sgm_match_planes_async
         return bool(fn(self.handle, planes.ctypes.data, fx, baseline, doffs, depth.ctypes.data))
 

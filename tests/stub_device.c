@@ -40,6 +40,8 @@ static int note(const char* name, int arg)
 int sgmd_device_count(void) { return 1; }
 int sgmd_device_is_gfx950(int o) { (void)o; return 1; }
 int sgmd_stream_create(int o, void** st) { (void)o; *st = malloc(8); return 0; }
+int sgmd_stream_create_cus(int o, void** st, int first, int count) { (void)o; *st = malloc(8); return note("stream_cus", first * 100 + count); }
+int sgmd_device_cus(int o, int* per, int* xcds) { (void)o; *per = 32; *xcds = 8; return 0; }
 int sgmd_stream_destroy(int o, void* st) { (void)o; free(st); return 0; }
 int sgmd_stream_sync(int o, void* st) { (void)o; (void)st; return note("sync", 0); }
 int sgmd_event_create(int o, void** e) { (void)o; *e = malloc(8); return 0; }
@@ -75,8 +77,8 @@ void sgmd_timer_destroy(int o, void* t) { (void)o; free(t); }
 int sgmd_timer_mark(int o, void* t, void* st, int i) { (void)o; (void)t; (void)st; (void)i; return 0; }
 int sgmd_timer_elapsed(int o, void* t, int a, int b, float* ms) { (void)o; (void)t; (void)a; (void)b; *ms = 0.f; return 0; }
 
-int sgmd_census(int o, void* st, const sgmd_geom* g, const void* l, const void* r, void* cl, void* cr, const void* need)
-{ (void)o; (void)st; (void)l; (void)r; (void)cl; (void)cr; (void)need; return note("census", g->B); }
+int sgmd_census(int o, void* st, const sgmd_geom* g, const void* l, const void* r, void* cl, void* cr, const void* need, int keep)
+{ (void)o; (void)st; (void)l; (void)r; (void)cl; (void)cr; (void)need; return note("census", g->B | (keep << 16)); }
 void sgmd_census_blocks(const sgmd_geom* g, int* bx, int* by) { *bx = (g->W + 63) / 64; *by = (g->H + 15) / 16; }
 int sgmd_cost(int o, void* st, const sgmd_geom* g, const void* cl, const void* cr, void* c)
 { (void)o; (void)st; (void)g; (void)cl; (void)cr; (void)c; return note("cost", 0); }
@@ -109,8 +111,10 @@ int sgmd_lrcheck(int o, void* st, const sgmd_geom* g, void* dl, const void* dr, 
 int sgmd_speckle(int o, void* st, const sgmd_geom* g, void* d, float diff, unsigned area, void* a, void* b, void* c)
 { (void)o; (void)st; (void)g; (void)d; (void)diff; (void)a; (void)b; (void)c; return note("speckle", (int)area); }
 size_t sgmd_median_scratch_bytes(const sgmd_geom* g) { return (size_t)g->W * g->H * 4; }
-int sgmd_median(int o, void* st, const sgmd_geom* g, void* d, void* s)
-{ (void)o; (void)st; (void)g; (void)d; (void)s; return note("median", 0); }
+static int g_median_stall;
+void stub_median_stall(int on) { g_median_stall = on; }      /* the next median launches report a band that gave up waiting */
+int sgmd_median(int o, void* st, const sgmd_geom* g, void* d, void* s, void* status)
+{ (void)o; (void)st; (void)g; (void)d; (void)s; if (g_median_stall && status) *(int*)status = 1; return note("median", 0); }
 int sgmd_depth(int o, void* st, const void* d, size_t n, float fx, float b, float doffs, void* out)
 { (void)o; (void)st; (void)d; (void)fx; (void)b; (void)doffs; (void)out; return note("depth", (int)n); }
 int sgmd_gray_planes(int o, void* st, const void* bgr, size_t n, int wr, void* gray)

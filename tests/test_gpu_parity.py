@@ -44,10 +44,14 @@ def inst(request):
     os.environ.pop("SGM_FUSED_WTA", None)
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture
 def gsgm():
+    """The reference-shaped global entry points.  Their default instance keeps its census buffers like the reference's statics
+    (a frame's border words depend on the frames of other shapes before it, tests/test_census_history.py), so
+    every test starts from SGM_Shutdown = a new process."""
     import soc_project_stereo_matching_amd as S
     g = S.SGM()
+    g.shutdown()
     yield g
     g.shutdown()
 
@@ -701,12 +705,12 @@ def test_tall_frames_in_a_batch(oracle):
 
 def test_depth_and_scoring_on_device(oracle):
     """SURVEY.md 8(f)-3 on device buffers: disparity -> depth in mm and RMSE / bad-pixel rate / valid count, against the host
-    restatement soc_project_stereo_matching_amd/platform.py (the reference's depth_image.py imports cv2, which is not
+    restatement oracle/platform_oracle.py (the reference's depth_image.py imports cv2, which is not
     installed: no reference-made vectors, "parity unpinned").  Depth: bit-exact (one float32 divide).  Scores: counts exact,
     rmse within 1e-6 relative (numpy sums float32 squares pairwise, the device sums doubles in block order)."""
     import torch
     import soc_project_stereo_matching_amd as S
-    from soc_project_stereo_matching_amd.platform import compare_depth, disparity_to_depth
+    from oracle.platform_oracle import compare_depth, disparity_to_depth
     w, h, d = 640, 200, 64
     left, right = oracle.synth_pair(w, h, d, 0xDE97)
     inst = S.SGMInstance(0)
@@ -745,10 +749,12 @@ def test_depth_and_scoring_on_device(oracle):
         inst.close()
 
 
+@pytest.mark.parametrize("split", [None, "post=0:4,main=4:28", "post=0:2,sum=2:10,main=12:20", "sum=0:0", "sum=0:8"])
 @pytest.mark.parametrize("batch", [1, 4])
-def test_overlapped_post_pass(oracle, batch):
+def test_overlapped_post_pass(oracle, batch, split):
     """sgm_set_overlap_post: LR check / speckle / median of a match on the instance's second stream beside the next match's
-    aggregation.  A stream of matches on ONE instance with one output buffer per match, results read after one
+    aggregation -- and sgm_set_stage_cus (`split`): the cost sum and / or the post pass on streams of their own, restricted to
+    some compute units of every XCD, the main stream to the others.  A stream of matches on ONE instance with one output buffer per match, results read after one
     sgm_synchronize at the end; then the same instance without Reset (Q14 accumulation through the lazy S materialisation,
     which shares scratch with the post pass), through the host-pointer async entry, and with the option switched off again."""
     import torch
@@ -757,7 +763,7 @@ def test_overlapped_post_pass(oracle, batch):
     w, h, d, n = 400, 120, 64, 5
     opt = default_option(d, min_speckle_area=20)
     inst = S.SGMInstance(0, batch=batch)
-    assert inst.set_overlap_post(True)
+    assert inst.set_cu_split(split) if split else inst.set_overlap_post(True)
     try:
         frames = [[oracle.synth_pair(w, h, d, 0x0FE7 + 10 * k + j) for j in range(batch)] for k in range(n)]
         ins = [(torch.from_numpy(np.stack([p[0] for p in fr])).cuda(), torch.from_numpy(np.stack([p[1] for p in fr])).cuda()) for fr in frames]
@@ -789,7 +795,10 @@ def test_overlapped_post_pass(oracle, batch):
         for j in range(batch):
             assert_same(O[j] if batch > 1 else O, oracle.run(frames[1][j][0], frames[1][j][1], opt)["final"], f"async frame {j}")
         # ... and off again: stream order of sgm_stream alone
-        assert inst.set_overlap_post(False) and inst.reset(w, h, opt)
+        assert inst.set_overlap_post(False)
+        for which in (inst.STAGE_SUM, inst.STAGE_POST, inst.STAGE_MAIN):
+            assert inst.set_stage_cus(which, 0, -1)
+        assert inst.reset(w, h, opt)
         assert inst.match_device(ins[2][0].data_ptr(), ins[2][1].data_ptr(), outs[2].data_ptr()) and inst.synchronize()
         assert_same(outs[2].cpu().numpy()[0], oracle.run(frames[2][0][0], frames[2][0][1], opt)["final"], "overlap off")
     finally:
@@ -814,7 +823,7 @@ def test_gray_from_planes(n, weight_r):
     device, all 256 values per channel present; dword path (n % 4 == 0) and byte path."""
     import torch
     import soc_project_stereo_matching_amd as S
-    from soc_project_stereo_matching_amd.platform import board_gray
+    from oracle.platform_oracle import board_gray
     rng = np.random.default_rng(n + weight_r)
     bgr = rng.integers(0, 256, (3, n), dtype=np.uint8)
     bgr[:, :3] = [[255, 0, 255], [255, 0, 0], [255, 255, 0]]                  # the extremes
@@ -835,11 +844,11 @@ def test_gray_from_planes(n, weight_r):
 def test_match_planes_depth(oracle, batch, overlap, pinned):
     """A test-platform frame end to end on the device: six colour planes in host memory -> grey -> SGM ->
     depth in mm in host memory.  Expected: the oracle's disparity for the board-grey images pushed through the platform's
-    depth formula (platform.py), bit for bit; the disparity map stays readable as stage 8; a stream of frames on one
+    depth formula (oracle/platform_oracle.py), bit for bit; the disparity map stays readable as stage 8; a stream of frames on one
     instance, pageable and pinned buffers, with and without the post pass on the second stream."""
     import soc_project_stereo_matching_amd as S
     from oracle.pyoracle import default_option
-    from soc_project_stereo_matching_amd.platform import board_gray, disparity_to_depth
+    from oracle.platform_oracle import board_gray, disparity_to_depth
     w, h, d = 322, 97, 48                                                    # odd row pitch: frames of a batch are not dword-aligned
     fx, baseline, doffs = 1733.74, 536.62, 0.0
     opt = S.default_option(d)

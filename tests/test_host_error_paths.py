@@ -395,3 +395,72 @@ def test_row_tiles_of_a_batch(host):
     assert names == ["census", "aggregate", "rows_in", "aggregate", "rows_out", "sum_wta_lr", "lrcheck"]
     assert [a for n, a in log(L) if n.startswith("rows_")] == [3 * B, 3 * B]      # one launch moves 3 directions x B frames
     L.sgm_destroy(s)
+
+
+def test_stage_streams_ordering(host):
+    """sgm_set_stage_cus: cost sum and post pass on streams of their own (restricted to some CUs of every XCD).  The sum
+    stream waits for the aggregation, the post stream for the sum; the NEXT aggregation waits for the previous cost sum (it
+    rewrites the planes that sum reads), the next cost sum for the previous post pass (it rewrites the maps that pass reads);
+    a failed launch drains every stream; count < 0 returns a group to the main stream."""
+    L = host
+    L.sgm_set_stage_cus.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.sgm_set_stage_cus.restype = C.c_bool
+    L.sgm_synchronize.argtypes = [C.c_void_p]
+    L.sgm_synchronize.restype = C.c_bool
+    s, opt = fresh(L)
+    L.stub_clear()
+    assert L.sgm_set_stage_cus(s, 2, 0, 2) and L.sgm_set_stage_cus(s, 1, 2, 10) and L.sgm_set_stage_cus(s, 0, 12, 20)
+    assert [a for n, a in log(L) if n == "stream_cus"] == [2, 210, 1220]          # first * 100 + count CUs per XCD
+    assert not L.sgm_set_stage_cus(s, 3, 0, 1)
+    f = Frame()
+    keep = ("sync", "h2d", "d2h", "alloc", "memset", "stream_cus")
+    assert L.sgm_reset(s, 48, 20, C.byref(opt))
+    L.stub_clear()
+    assert L.sgm_match_device(s, *f.args())
+    assert [n for n, _ in log(L, drop=keep)] == ["census", "aggregate", "event_record", "wait_event", "sum_wta_lr", "event_record",
+                                                   "wait_event", "lrcheck", "speckle", "median", "event_record"]
+    L.stub_clear()
+    assert L.sgm_reset(s, 48, 20, C.byref(opt)) and L.sgm_match_device(s, *f.args())
+    names = [n for n, _ in log(L, drop=keep)]
+    # previous sum still reads the planes -> wait; ...; previous post pass still reads the maps -> wait before the sum
+    assert names[:7] == ["wait_event", "census", "aggregate", "event_record", "wait_event", "wait_event", "sum_wta_lr"]
+    # a refused launch on the post stream: everything is drained (three streams), nothing stays pending
+    L.stub_clear()
+    L.stub_fail_at(b"speckle", 0)
+    assert L.sgm_reset(s, 48, 20, C.byref(opt)) and not L.sgm_match_device(s, *f.args())
+    assert [L.stub_log_name(i).decode() for i in range(L.stub_log_size())][-3:] == ["sync"] * 3
+    L.stub_clear()
+    assert L.sgm_reset(s, 48, 20, C.byref(opt)) and L.sgm_match_device(s, *f.args())
+    assert [n for n, _ in log(L, drop=keep)][:2] == ["census", "aggregate"]
+    # sum on its own stream, post pass not: the post pass follows the sum there and the next aggregation waits for all of it
+    assert L.sgm_set_stage_cus(s, 2, 0, -1) and L.sgm_reset(s, 48, 20, C.byref(opt))
+    L.stub_clear()
+    assert L.sgm_match_device(s, *f.args())
+    assert [n for n, _ in log(L, drop=keep)] == ["census", "aggregate", "event_record", "wait_event", "sum_wta_lr", "event_record",
+                                                   "lrcheck", "speckle", "median", "event_record"]
+    # back to one stream
+    assert L.sgm_set_stage_cus(s, 1, 0, -1) and L.sgm_set_stage_cus(s, 0, 0, -1) and L.sgm_reset(s, 48, 20, C.byref(opt))
+    L.stub_clear()
+    assert L.sgm_match_device(s, *f.args())
+    assert [n for n, _ in log(L, drop=keep)] == ["census", "aggregate", "sum_wta_lr", "lrcheck", "speckle", "median"]
+    L.sgm_destroy(s)
+
+
+def test_median_band_that_gave_up_fails_the_match(host):
+    """The chained median kernel of tall frames polls the band above a bounded number of times; a band that gives up sets a word
+    of page-locked host memory (sgmd_median's status argument).  The host reads it after every wait for the streams: the
+    match that produced the map fails (sgm_synchronize / sgm_match_wait / sgm_match return false), the next one is clean."""
+    L = host
+    L.sgm_synchronize.argtypes = [C.c_void_p]
+    L.sgm_synchronize.restype = C.c_bool
+    L.stub_median_stall.argtypes = [C.c_int]
+    s, opt = fresh(L)
+    f = Frame()
+    L.stub_median_stall(1)
+    assert L.sgm_match_device(s, *f.args())            # queued; the failure shows when the host waits
+    assert not L.sgm_synchronize(s)
+    assert L.sgm_reset(s, 48, 20, C.byref(opt))
+    assert not L.sgm_match(s, *f.args())               # blocking host-pointer form: false, the output is not handed over
+    L.stub_median_stall(0)
+    assert L.sgm_reset(s, 48, 20, C.byref(opt)) and L.sgm_match(s, *f.args()) and L.sgm_synchronize(s)
+    L.sgm_destroy(s)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Shader clock during the aggregation launches of a running benchmark loop (diagnostics, on the GPU box):
-batches of 8 KITTI frames, two instances in flight for a few seconds, then s_memtime / s_memrealtime of the last launch."""
+batches of 8 KITTI frames, two instances in flight for a few seconds, then s_memtime / s_memrealtime of the last launch.
+Needs a build with the probe compiled in (the product build has none):
+    tools/build_variant.sh clock CLOCK_PROBE=1 && SGM_LIBRARY_PATH=variants/clock/libsgm_mi355x.so python tools/agg_clock.py"""
 import ctypes as C
 import os
 import sys
@@ -34,7 +36,8 @@ for n_inst in ((1,) if len(sys.argv) > 4 else (1, 2)):
             torch.cuda.synchronize()
     torch.cuda.synchronize()
     out = (C.c_ulonglong * 2)()
-    S.load_library().sgmd_debug_clock(0, out)
+    if S.load_library().sgmd_debug_clock(0, out) != 0:
+        raise SystemExit("this library was built without the clock probe: tools/build_variant.sh clock CLOCK_PROBE=1")
     i0 = insts[0]
     i0.enable_timing(True)
     for _ in range(3):

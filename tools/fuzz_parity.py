@@ -90,7 +90,7 @@ def pipe_case(orc, rng, w, h, d, opt, seed, kw):
 
 def planes_case(orc, rng, w, h, d, opt, oopt, seed, kw):
     """a batch of test-platform frames (six colour planes each) through sgm_match_planes against oracle -> depth formula"""
-    from soc_project_stereo_matching_amd.platform import board_gray, disparity_to_depth
+    from oracle.platform_oracle import board_gray, disparity_to_depth
     B = int(rng.integers(1, 4))
     fx, baseline, doffs = float(rng.choice([1733.74, 3979.9, 100.0])), float(rng.choice([536.62, 193.0])), float(rng.choice([0.0, 124.3, -3.0]))
     planes = np.empty((B, 6, h, w), np.uint8)

@@ -26,7 +26,7 @@ W, H = 1280, 720
 def main():
     import soc_project_stereo_matching_amd as S
     from oracle.pyoracle import Oracle, default_option
-    from soc_project_stereo_matching_amd.platform import board_gray, disparity_to_depth
+    from oracle.platform_oracle import board_gray, disparity_to_depth
     d = int(sys.argv[1]) if len(sys.argv) > 1 else 128
     budget = float(os.environ.get("RATE_SECONDS", "4"))
     fx, baseline, doffs = 1733.74, 536.62, 0.0
