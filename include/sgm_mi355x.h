@@ -157,6 +157,10 @@ bool          sgm_set_overlap_post(sgm_instance* s, int enable);
  * sgm_stream(s).  Ignored in row-tile mode.  The instance must be idle (the call waits for it). */
 enum { SGM_STAGE_MAIN = 0, SGM_STAGE_SUM = 1, SGM_STAGE_POST = 2 };
 bool          sgm_set_stage_cus(sgm_instance* s, int which, int first_cu_per_xcd, int cus_per_xcd);
+/* The same with a dispatch priority instead of a CU range: the group gets a stream of its own on all CUs whose waiting
+ * workgroups the dispatcher serves before (priority < 0) or after (> 0) those of normal streams (clamped to the device's
+ * range).  Replaces a CU range set before. */
+bool          sgm_set_stage_priority(sgm_instance* s, int which, int priority);
 /* The HIP stream (hipStream_t as void*) the instance launches on, e.g. to record events. */
 void*         sgm_stream(sgm_instance* s);
 

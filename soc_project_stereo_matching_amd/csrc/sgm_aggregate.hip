@@ -3,6 +3,8 @@
 // kernels for negative P1 live in sgm_aggregate_generic.hip (their own translation unit: parallel build)
 bool sgmd_aggregate_launch_generic(int lpp, int dpl, const AggArgs* a, int blocks, int pad, hipStream_t st);
 bool sgmd_aggregate_launch_volume(int dpl, const AggArgs* a, int blocks, int pad, hipStream_t st);
+// ... and those with the shortcuts for ordinary penalties in sgm_aggregate_fast.hip
+bool sgmd_aggregate_launch_fast(int lpp, int dpl, const AggArgs* a, int blocks, int pad, int hl, hipStream_t st);
 
 static int aggregate_any(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* paths, const void* img_left,
                          const void* census_l, const void* census_r, const void* cost, const void* lut, void* planes,
@@ -47,7 +49,12 @@ static int aggregate_any(int ord, void* stream, const sgmd_geom* g, const sgmd_p
     hipStream_t st = (hipStream_t)stream;
     bool launched;
     if (cost)           launched = sgmd_aggregate_launch_volume(g->DPL, &a, blocks, pad ? 1 : 0, st);
-    else if (a.p1 >= 0) launched = launch_aggregate_key<true>(g->LPP, g->DPL, a, blocks, pad, g->HL, st);
+    else if (a.p1 >= 0) {
+        // ordinary penalties (agg_step_nn's FAST conditions) unless the host asks for the plain non-negative-P1 step
+        const bool fast = paths->allow_fast && a.p1 <= 31488 && paths->pen_max <= 223;
+        launched = fast ? sgmd_aggregate_launch_fast(g->LPP, g->DPL, &a, blocks, pad ? 1 : 0, g->HL, st)
+                        : launch_aggregate_key<1>(g->LPP, g->DPL, a, blocks, pad, g->HL, st);
+    }
     else                launched = sgmd_aggregate_launch_generic(g->LPP, g->DPL, &a, blocks, pad ? 1 : 0, st);
     if (!launched) {
         fprintf(stderr, "sgm_mi355x: unsupported lanes-per-pixel/DPL combination %d/%d\n", g->LPP, g->DPL);

@@ -5,7 +5,7 @@
 
 bool sgmd_aggregate_launch_generic(int lpp, int dpl, const AggArgs* a, int blocks, int pad, hipStream_t st)
 {
-    return launch_aggregate_key<false>(lpp, dpl, *a, blocks, pad != 0, 0, st);
+    return launch_aggregate_key<0>(lpp, dpl, *a, blocks, pad != 0, 0, st);
 }
 
 // volume-fed kernels (wide census windows): generic step, 16 lanes per pixel

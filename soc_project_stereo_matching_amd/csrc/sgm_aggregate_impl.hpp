@@ -184,7 +184,39 @@ static __device__ __forceinline__ unsigned shl16_add(unsigned a, unsigned b)
     asm("v_lshl_add_u32 %0, %1, 16, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-template <int DPL, bool PAD, int LPP>
+// FAST (NN == 2): two more things the host guarantees for ordinary penalties (sgm_aggregate.hip: 0 <= P1 <= 31488 and
+// max(P1, P2_init) <= 223):
+//  * every operand of the neighbour minimum is a 16-bit pattern below 0x7C00 (L <= 255, L + P1 <= 31743), i.e. a positive finite
+//    binary16 -- and those order exactly like their bit patterns, so gfx950's packed three-way v_pk_minimum3_f16 IS the unsigned
+//    minimum of (Lp(d-1)+P1, Lp(d+1)+P1, Lp(d)): one instruction instead of two v_pk_min_u16 (no value is ever interpreted as a
+//    number: denormal patterns pass through unchanged, tools/ubench/pk_min3_probe.hip checks all 31744^2 pairs); the in-lane tree
+//    of the row minimum halves the same way;
+//  * away from the left border C <= 32 and the bracket <= P2' <= 223, so C + bracket < 256 and the uint8 truncation (ref :343,
+//    Q7) is the identity there: the AND only runs on the (wave-uniform, rare) border steps, where C = 127 can wrap.
+static __device__ __forceinline__ us2 pk_min3_f16(us2 a, us2 b, us2 c)
+{
+    unsigned r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(as_u(a)), "v"(as_u(b)), "v"(as_u(c)));
+    return as_p(r);
+}
+template <int N, bool FAST>
+static __device__ __forceinline__ us2 pk_min_tree(const us2 (&v)[N])
+{
+    if constexpr (!FAST || N < 3) {
+        us2 m = v[0];
+#pragma unroll
+        for (int j = 1; j < N; ++j) m = pk_min(m, v[j]);
+        return m;
+    } else {
+        us2 m = pk_min3_f16(v[0], v[1], v[2]);
+        int j = 3;
+#pragma unroll
+        for (; j + 1 < N; j += 2) m = pk_min3_f16(m, v[j], v[j + 1]);
+        if (j < N) m = pk_min(m, v[j]);
+        return m;
+    }
+}
+template <int DPL, bool PAD, int LPP, bool FAST = false>
 static __device__ __forceinline__ unsigned agg_step_nn(unsigned cl, const CensusVec<DPL>& cv, int lim, bool border,
                                                        us2 (&Lp)[DPL / 2], unsigned min_prev, unsigned pen16, us2 p1v,
                                                        const us2 (&padmask)[DPL / 2], bool first_lane, bool last_lane,
@@ -215,8 +247,9 @@ static __device__ __forceinline__ unsigned agg_step_nn(unsigned cl, const Census
         // no carry or borrow crosses the halves -- Lp <= 255, 0 <= P1 <= 32767, and every candidate is >= min_prev
         const us2 dm1 = as_p(__builtin_amdgcn_alignbit(as_u(Lp[j]), below, 16) + p1u);
         const us2 dp1 = as_p(__builtin_amdgcn_alignbit(above, as_u(Lp[j]), 16) + p1u);
-        us2 m = pk_min(dm1, dp1);
-        m = pk_min(m, Lp[j]);
+        us2 m;
+        if constexpr (FAST) m = pk_min3_f16(dm1, dp1, Lp[j]);
+        else m = pk_min(pk_min(dm1, dp1), Lp[j]);
         md[j] = as_u(pk_min(as_p(as_u(m) - mp), p2v));
         const unsigned lo = bcnt_acc(cl ^ cv.r[DPL - 1 - 2 * j], md[j]);              // C(2j) + md, high half = md's
         w[j] = shl16_add((unsigned)__popc(cl ^ cv.r[DPL - 2 - 2 * j]), lo);           // + C(2j+1) << 16
@@ -231,13 +264,13 @@ static __device__ __forceinline__ unsigned agg_step_nn(unsigned cl, const Census
     us2 Ln[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-        unsigned r = w[j] & 0x00FF00FFu;                                              // uint8 truncation (Q7)
+        unsigned r = w[j];
+        if constexpr (FAST) { if (border) r &= 0x00FF00FFu; }                         // only C = 127 can pass 255 (see above)
+        else r &= 0x00FF00FFu;                                                        // uint8 truncation (Q7)
         if (PAD) r |= as_u(padmask[j]);
         Ln[j] = as_p(r);
     }
-    us2 m = Ln[0];
-#pragma unroll
-    for (int j = 1; j < NP; ++j) m = pk_min(m, Ln[j]);
+    const us2 m = pk_min_tree<NP, FAST>(Ln);
 #pragma unroll
     for (int j = 0; j < NP; ++j) Lp[j] = Ln[j];
     pack_cells<DPL>(Ln, packed_out);
@@ -255,7 +288,7 @@ enum { AGG_H = 0, AGG_V = 1, AGG_D = 2 };
 // instructions per step instead of the ~17 of the reference's two-tracker state machine (which W <= H still needs:
 // there the off-by-one tracker makes lines wrap early).
 // VOL: the matching cost comes from a materialised volume (wide census windows) instead of the census images.
-template <int DPL, bool PAD, int LPP, int KIND, bool NN, bool WIDE = false, bool VOL = false>
+template <int DPL, bool PAD, int LPP, int KIND, int NN, bool WIDE = false, bool VOL = false>
 static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFrame& fr, const unsigned short* lut_s,
                                                    const unsigned* lut32_s, int dir, int grp)
 {
@@ -440,7 +473,7 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
         const unsigned dg = __builtin_amdgcn_sad_u8((unsigned)g, (unsigned)g_prev, 0u);   // |g - g_prev| (grey values: one byte)
         CellVec<DPL> packed;
         if constexpr (NN) {
-            min_prev = agg_step_nn<DPL, PAD, LPP>(clb[u], cb[u], lim, __any(lim < DPL - 1) != 0, Lp, min_prev, lut32_s[dg], p1v,
+            min_prev = agg_step_nn<DPL, PAD, LPP, NN == 2>(clb[u], cb[u], lim, __any(lim < DPL - 1) != 0, Lp, min_prev, lut32_s[dg], p1v,
                                                   padmask, first_lane, last_lane, packed);
             if (refill) {                                                      // the slot's census words are consumed now
                 advance();
@@ -593,8 +626,9 @@ static __device__ __forceinline__ void agg_anomalous(const AggArgs& a, const Agg
     }
 }
 
-// NN: the step for non-negative P1 (agg_step_nn); the generic step only serves negative P1, for which the host
-// keeps to 16 lanes per pixel everywhere (sgm_host.c), so only those combinations are instantiated without NN
+// NN: 0 = the generic step (any penalties; serves negative P1, for which the host keeps to 16 lanes per pixel everywhere,
+// sgm_host.c, so only those combinations are instantiated), 1 = the step for non-negative P1 (agg_step_nn), 2 = the same with the
+// FAST shortcuts for ordinary penalties (sgm_aggregate_fast.hip)
 // Diagnostics, compiled in only with -DSGM_CLOCK_PROBE (make CLOCK_PROBE=1; tools/agg_clock.py builds such a variant): the shader
 // clock the launch runs at -- s_memtime (shader-clock ticks) against s_memrealtime (100 MHz) over the lifetime of one long-running
 // wave (block 0 = horizontal lines of frame 0: W-1 steps); read back with sgmd_debug_clock(), which covers the kernels of
@@ -603,7 +637,7 @@ static __device__ __forceinline__ void agg_anomalous(const AggArgs& a, const Agg
 static __device__ unsigned long long g_sgm_agg_clock[2];
 #endif
 
-template <int DPL, bool PAD, int LPP, int HL, bool NN, bool VOL = false>
+template <int DPL, bool PAD, int LPP, int HL, int NN, bool VOL = false>
 __global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
 {
 #ifdef SGM_CLOCK_PROBE
@@ -663,7 +697,7 @@ __global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
     else                     agg_regular<DPL, PAD, LPP, AGG_D, NN, false, VOL>(a, fr, lut_s, lut32_s, dir, grp);
 }
 
-template <int DPL, int LPP, int HL, bool NN>
+template <int DPL, int LPP, int HL, int NN>
 static bool launch_aggregate_hl(const AggArgs& a, int blocks, bool pad, hipStream_t st)
 {
     constexpr int per = (HL != 0) ? DPL * LPP / HL : DPL;                 // disparities per lane on the horizontal lines
@@ -675,7 +709,7 @@ static bool launch_aggregate_hl(const AggArgs& a, int blocks, bool pad, hipStrea
     }
     return false;
 }
-template <int DPL, int LPP, bool NN>
+template <int DPL, int LPP, int NN>
 static void launch_aggregate(const AggArgs& a, int blocks, bool pad, int hl, hipStream_t st)
 {
     if constexpr (NN) {
@@ -688,7 +722,7 @@ static void launch_aggregate(const AggArgs& a, int blocks, bool pad, int hl, hip
 // (DPL, LPP): disparities per lane x lanes per pixel = Dp.  16 lanes per pixel (4 lines per wave) gives the shortest
 // serial step; 8 lanes per pixel (8 lines per wave) spends ~40 % fewer VALU instructions per cell and is what a
 // batch of frames (VALU-bound) uses.  Returns false for a combination that is not instantiated.
-template <bool NN>
+template <int NN>
 static bool launch_aggregate_key(int lpp, int dpl, const AggArgs& a, int blocks, bool pad, int hl, hipStream_t st)
 {
     switch (lpp * 100 + dpl) {

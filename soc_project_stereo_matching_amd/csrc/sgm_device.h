@@ -22,6 +22,7 @@ int   sgmd_stream_create(int ordinal, void** stream);
  * bit i is CU i / xcds of XCD i % xcds).  count <= 0: an ordinary stream on all CUs */
 int   sgmd_stream_create_cus(int ordinal, void** stream, int first_per_xcd, int count_per_xcd);
 int   sgmd_device_cus(int ordinal, int* cus_per_xcd, int* xcds);     /* 32 x 8 on MI355X */
+int   sgmd_stream_create_prio(int ordinal, void** stream, int priority);   /* 0 normal, < 0 higher, > 0 lower (clamped) */
 int   sgmd_stream_destroy(int ordinal, void* stream);
 int   sgmd_stream_sync(int ordinal, void* stream);
 /* events without timing, for ordering one stream behind another */
@@ -29,6 +30,9 @@ int   sgmd_event_create(int ordinal, void** event);
 void  sgmd_event_destroy(int ordinal, void* event);
 int   sgmd_event_record(int ordinal, void* event, void* stream);
 int   sgmd_stream_wait_event(int ordinal, void* stream, void* event);
+int   sgmd_event_sync(int ordinal, void* event);                     /* the host waits */
+int   sgmd_set_device(int ordinal);                                  /* the calling thread's current device (for libraries such as RCCL) */
+int   sgmd_mem_info(int ordinal, size_t* free_bytes, size_t* total_bytes);
 int   sgmd_alloc(int ordinal, void** dptr, size_t bytes);
 int   sgmd_free(int ordinal, void* dptr);
 int   sgmd_alloc_pinned(int ordinal, void** hptr, size_t bytes);
@@ -77,6 +81,8 @@ typedef struct {
     int anom_line[8];          /* line index whose first step trips the wrong edge test, or -1 */
     int ghost_zero;            /* 1: W >= H, the anomalous wave zeroes the cells no line visits */
     int p1;
+    int pen_max;               /* largest entry of the adaptive-P2 table = max(P1, P2_init, 0): picks the aggregation step family */
+    int allow_fast;            /* 0: never the FAST step family (sgm_aggregate_fast.hip), whatever the penalties (tests run both) */
     int dir_mask;              /* bit d: run direction d in this launch (0xFF normally; a tile sweep runs a subset) */
     int run_anom;              /* 1: run the anomalous diagonal lines in this launch (whole frame, never tiled) */
 } sgmd_paths;

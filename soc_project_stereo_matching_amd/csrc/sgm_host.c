@@ -23,6 +23,10 @@
 
 #define TIMING_RING 64
 enum { T_CENSUS, T_COST, T_AGGREGATE, T_SUM, T_WTA, T_LRCHECK, T_SPECKLE, T_MEDIAN, T_COUNT };
+/* event marks of a match: 0 .. T_COUNT bracket the stages in order; one more, M_SUM_BEGIN, sits right in front of the cost sum
+ * BEHIND its waits for other streams' events, so that "sum" is the kernel's time and not the wait for the previous post pass */
+#define M_SUM_BEGIN (T_COUNT + 1)
+#define MARKS_PER_MATCH (T_COUNT + 2)
 static const char* const k_stage_names[T_COUNT] = {"census", "cost", "aggregate", "sum", "wta", "lrcheck", "speckle", "median"};
 
 /* reference direction order, SemiGlobalMatching.c:213-220 */
@@ -293,6 +297,21 @@ bool sgm_set_stage_cus(sgm_instance* s, int which, int first_per_xcd, int count_
     return true;
 }
 
+/* the group's own stream, on all CUs, with a dispatch priority (include/sgm_mi355x.h) */
+bool sgm_set_stage_priority(sgm_instance* s, int which, int priority)
+{
+    if (!s || which < SGM_STAGE_MAIN || which > SGM_STAGE_POST) return false;
+    if (!sgm_match_wait(s) || sync_streams(s) != 0) return false;
+    void** slot = which == SGM_STAGE_MAIN ? &s->stream : (which == SGM_STAGE_SUM ? &s->sum_stream : &s->post_stream);
+    void* fresh = NULL;
+    if (!ensure_stage_events(s) || sgmd_stream_create_prio(s->device, &fresh, priority) != 0) return false;
+    if (*slot) sgmd_stream_destroy(s->device, *slot);
+    *slot = fresh;
+    s->cu_first[which] = s->cu_count[which] = 0;
+    if (which == SGM_STAGE_POST) s->overlap_post = 1;
+    return true;
+}
+
 bool sgm_set_overlap_post(sgm_instance* s, int enable)
 {
     if (!s) return false;
@@ -331,7 +350,7 @@ void* sgm_stream(sgm_instance* s) { return s ? s->stream : NULL; }
 void sgm_enable_timing(sgm_instance* s, int enable)
 {
     if (!s) return;
-    if (enable && !s->timer && sgmd_timer_create(s->device, &s->timer, TIMING_RING * (T_COUNT + 1)) != 0) return;
+    if (enable && !s->timer && sgmd_timer_create(s->device, &s->timer, TIMING_RING * MARKS_PER_MATCH) != 0) return;
     s->timing = enable;
     /* (re-)enabling starts a new statistics window: drop what was recorded before */
     sync_streams(s);
@@ -622,6 +641,14 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
 
     s->paths.ndirs = (s->honor_num_paths && option->num_paths == 4) ? 4 : 8;    /* Q1 */
     s->paths.p1 = option->p1;
+    {
+        uint16_t lut[256];
+        build_p2_table(option->p1, option->p2_init, lut);
+        s->paths.pen_max = 0;
+        for (int a = 0; a < 256; ++a) if (lut[a] > s->paths.pen_max) s->paths.pen_max = lut[a];
+        const char* e = getenv("SGM_AGG_FAST");                  /* 0: keep the plain non-negative-P1 step (parity tests run both) */
+        s->paths.allow_fast = (e && *e) ? atoi(e) != 0 : 1;
+    }
     for (int d = 0; d < 8; ++d) {
         s->paths.dx[d] = k_dir_dx[d];
         s->paths.dy[d] = k_dir_dy[d];
@@ -687,7 +714,7 @@ bool sgm_reset(sgm_instance* s, uint16_t width, uint16_t height, const SGMOption
 
 static void mark_on(sgm_instance* s, void* stream, int idx)
 {
-    if (s->timing && s->timer) sgmd_timer_mark(s->device, s->timer, stream, s->ring_next * (T_COUNT + 1) + idx);
+    if (s->timing && s->timer) sgmd_timer_mark(s->device, s->timer, stream, s->ring_next * MARKS_PER_MATCH + idx);
 }
 static void mark(sgm_instance* s, int idx) { mark_on(s, s->stream, idx); }
 
@@ -843,6 +870,7 @@ static bool run_pipeline(sgm_instance* s, const void* d_left, const void* d_righ
     }
     /* the cost sum writes d_out and the right-view map, which the previous match's post pass may still be reading */
     if (s->post_pending) LAUNCH(sgmd_stream_wait_event(dev, sts, s->ev_post));
+    mark_on(s, sts, M_SUM_BEGIN);
     LAUNCH(sum_and_wta(s, sts, d_out, true));                                                       /* .c:94 sum, .c:99, .c:105 */
     if (s->keep_stages) LAUNCH(sgmd_d2d_async(dev, sts, s->d_snap_wta, d_out, px_bytes));
     mark_on(s, sts, 5);
@@ -1017,9 +1045,12 @@ static int wait_for_result(sgm_instance* s, void* stream)
     return sgmd_stream_wait_event(s->device, stream, ev);
 }
 
+/* D2H of a result behind the match that produced it.  No event is recorded behind the copy: every entry point that could
+ * overwrite the copy's source (the instance's own d_disp / d_depth) starts with sgm_match_wait, i.e. after the copy has
+ * completed -- and an event record queued behind a D2H costs the pipelined host-pointer path 3 % (measured: 3830 -> 3700 fps) */
 static bool queue_result_copy(sgm_instance* s, void* host_dst, const void* d_src, size_t bytes)
 {
-    return sgmd_d2h_async(s->device, result_stream(s), host_dst, d_src, bytes) == 0 && rerecord_result_event(s) == 0;
+    return sgmd_d2h_async(s->device, result_stream(s), host_dst, d_src, bytes) == 0;
 }
 
 static void collect_timing(sgm_instance* s)
@@ -1028,11 +1059,12 @@ static void collect_timing(sgm_instance* s)
     /* every match recorded since the last collection (the stream is idle here), oldest first */
     while (s->ring_pending > 0) {
         const int set = ((s->ring_next - s->ring_pending) % TIMING_RING + TIMING_RING) % TIMING_RING;
-        const int base = set * (T_COUNT + 1);
+        const int base = set * MARKS_PER_MATCH;
         --s->ring_pending;
         float ms[T_COUNT];
         bool ok = true;
-        for (int i = 0; i < T_COUNT && ok; ++i) ok = sgmd_timer_elapsed(s->device, s->timer, base + i, base + i + 1, &ms[i]) == 0;
+        for (int i = 0; i < T_COUNT && ok; ++i)
+            ok = sgmd_timer_elapsed(s->device, s->timer, base + (i == T_SUM ? M_SUM_BEGIN : i), base + i + 1, &ms[i]) == 0;
         if (!ok) continue;
         for (int i = 0; i < T_COUNT; ++i) {
             s->last_ms[i] = ms[i];
@@ -1173,9 +1205,9 @@ bool sgm_match_planes_async(sgm_instance* s, const uint8_t* planes, float fx, fl
     }
     ok = ok && run_pipeline(s, s->d_left, s->d_right, s->d_disp);
     void* st = result_stream(s);
-    ok = ok && sgmd_depth(dev, st, s->d_disp, px, fx, baseline, doffs, s->d_depth) == 0 &&
-         sgmd_d2h_async(dev, st, out_pinned ? (void*)depth : s->h_disp, s->d_depth, px * sizeof(float)) == 0;
-    if (ok) ok = rerecord_result_event(s) == 0;                  /* the next match's cost sum waits for these too */
+    /* the depth conversion reads the map the next match's cost sum rewrites: "result done" moves behind it (not behind the copy) */
+    ok = ok && sgmd_depth(dev, st, s->d_disp, px, fx, baseline, doffs, s->d_depth) == 0 && rerecord_result_event(s) == 0 &&
+         queue_result_copy(s, out_pinned ? (void*)depth : s->h_disp, s->d_depth, px * sizeof(float));
     if (!ok) {
         sync_streams(s);
         return false;

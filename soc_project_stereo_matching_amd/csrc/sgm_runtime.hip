@@ -60,6 +60,20 @@ int sgmd_stream_create_cus(int ord, void** stream, int first_per_xcd, int count_
     *stream = (void*)s;
     return 0;
 }
+// priority: 0 normal, < 0 higher, > 0 lower (clamped to the device's range): the dispatcher serves a higher-priority queue's
+// waiting workgroups first whenever execution resources free up
+int sgmd_stream_create_prio(int ord, void** stream, int priority)
+{
+    HIP_TRY(hipSetDevice(ord));
+    int least = 0, greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));        // numerically: least >= greatest
+    if (priority > least) priority = least;
+    if (priority < greatest) priority = greatest;
+    hipStream_t s;
+    HIP_TRY(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority));
+    *stream = (void*)s;
+    return 0;
+}
 int sgmd_stream_destroy(int ord, void* stream)
 {
     HIP_TRY(hipSetDevice(ord));
@@ -96,6 +110,23 @@ int sgmd_stream_wait_event(int ord, void* stream, void* event)
 {
     HIP_TRY(hipSetDevice(ord));
     HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return 0;
+}
+int sgmd_event_sync(int ord, void* event)
+{
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipEventSynchronize((hipEvent_t)event));
+    return 0;
+}
+int sgmd_set_device(int ord)
+{
+    HIP_TRY(hipSetDevice(ord));
+    return 0;
+}
+int sgmd_mem_info(int ord, size_t* free_bytes, size_t* total_bytes)
+{
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipMemGetInfo(free_bytes, total_bytes));
     return 0;
 }
 int sgmd_alloc(int ord, void** dptr, size_t bytes)

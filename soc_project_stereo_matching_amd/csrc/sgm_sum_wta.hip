@@ -143,7 +143,10 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
 #endif
     constexpr int R = Dp + (TIGHT ? 1 : 2) * COLS;
     static_assert(R % COLS == 0, "a ring slot must always belong to the same px");
-    __shared__ unsigned short ring[R * LD];
+    // slots R .. R + MIR - 1 mirror slots 0 .. MIR - 1 (written together): the DPL consecutive slots a lane gathers its piece of
+    // the right view's diagonal from then never wrap, so the gather is one base address per lane and immediate offsets
+    constexpr int MIR = DPL;
+    __shared__ unsigned short ring[(R + MIR) * LD];
     __shared__ unsigned ex_val[SUMLR_MAX_EXTRA * (Dp / 4)];
     __shared__ int ex_col[SUMLR_MAX_EXTRA];
 
@@ -206,18 +209,24 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
         if (base >= R) base -= R;
         unsigned key[DPL], val[DPL];
         unsigned kmin = 0xFFFFFFFFu;
+        int first = base + sub * DPL;                                    // slot of this lane's first disparity; the others follow (mirror)
+        if (first >= R) first -= R;
+        const unsigned short* const diag = &ring[umad24((unsigned)first, (unsigned)LD, (unsigned)(sub * DPL))];
 #pragma unroll
-        for (int i = 0; i < DPL; ++i) {
-            const int k = sub * DPL + i;
-            int sl = base + k;
-            if (sl >= R) sl -= R;
-            val[i] = ring[umad24((unsigned)sl, (unsigned)LD, (unsigned)k)];   // padding disparities hold 65535
-        }
+        for (int i = 0; i < DPL; ++i) val[i] = diag[i * (LD + 1)];      // padding disparities and columns past the image hold 65535
+        if (D == Dp) {                                                   // wave-uniform: no padding disparities, every slot read was written
 #pragma unroll
-        for (int i = 0; i < DPL; ++i) {
-            const int k = sub * DPL + i;
-            key[i] = (k < D) ? ((val[i] << 16) | (unsigned)k) : 0xFFFFFFFFu;
-            kmin = min(kmin, key[i]);
+            for (int i = 0; i < DPL; ++i) {
+                key[i] = (val[i] << 16) | (unsigned)(sub * DPL + i);
+                kmin = min(kmin, key[i]);
+            }
+        } else {                                                         // padding disparities reach into slots ahead of the newest column
+#pragma unroll
+            for (int i = 0; i < DPL; ++i) {
+                const int k = sub * DPL + i;
+                key[i] = (k < D) ? ((val[i] << 16) | (unsigned)k) : 0xFFFFFFFFu;
+                kmin = min(kmin, key[i]);
+            }
         }
         const unsigned kbest = row_allmin<16>(kmin);
         // runner-up: keys are distinct (they carry d), so key - kbest - 1 (mod 2^32) sends the best to the top
@@ -338,6 +347,10 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
                 pr[m] = inside ? (pr[m] | padpair[m]) : 0xFFFFFFFFu;
                 dst[m] = pr[m];
             }
+            if (slot < MIR) {                                            // ... and its mirror behind the ring
+#pragma unroll
+                for (int m = 0; m < NPAIR; ++m) dst[(R * LD) / 2 + m] = pr[m];
+            }
         }
         // ---- left-view WTA over the 16 lanes of the pixel (as in sgm_sum_wta_k); padding disparities carry 65535,
         //      so their keys lose against every real one ----
@@ -375,6 +388,10 @@ __global__ __launch_bounds__(THREADS) void sgm_sum_wta_lr_k(const uint8_t* __res
         unsigned* dst = reinterpret_cast<unsigned*>(&ring[umad24((unsigned)slot, (unsigned)LD, (unsigned)(sub * DPL))]);
 #pragma unroll
         for (int i = 0; i < DPL; i += 2) dst[i >> 1] = 0xFFFFFFFFu;
+        if (slot < MIR) {
+#pragma unroll
+            for (int i = 0; i < DPL; i += 2) dst[(R * LD) / 2 + (i >> 1)] = 0xFFFFFFFFu;
+        }
         finish_views(xa + it * COLS + px, false, 0u, 0u);
         next_slot();
     }

@@ -96,8 +96,11 @@ def load_library() -> C.CDLL:
     L.sgm_set_honor_num_paths.argtypes = [C.c_void_p, C.c_int]
     L.sgm_set_overlap_post.argtypes = [C.c_void_p, C.c_int]
     L.sgm_set_overlap_post.restype = C.c_bool
-    L.sgm_set_stage_cus.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
-    L.sgm_set_stage_cus.restype = C.c_bool
+    if hasattr(L, "sgm_set_stage_cus"):       # (SGM_LIBRARY_PATH may point an A/B run at a build of older sources)
+        L.sgm_set_stage_cus.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.sgm_set_stage_cus.restype = C.c_bool
+        L.sgm_set_stage_priority.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.sgm_set_stage_priority.restype = C.c_bool
     L.sgm_set_census_window.argtypes = [C.c_void_p, C.c_int, C.c_int]
     L.sgm_set_census_window.restype = C.c_bool
     L.sgm_set_reference_view.argtypes = [C.c_void_p, C.c_int]
@@ -355,6 +358,9 @@ class SGMInstance(_StageReader):
         ok = True
         for item in filter(None, (t.strip() for t in spec.split(","))):
             name, _, rng = item.partition("=")
+            if rng.startswith("p"):                           # 'sum=p-1': own stream with dispatch priority -1 (higher)
+                ok = bool(self.lib.sgm_set_stage_priority(self.handle, which[name], int(rng[1:]))) and ok
+                continue
             first, _, count = (rng or "0:0").partition(":")
             ok = self.set_stage_cus(which[name], int(first or 0), int(count or 0)) and ok
         return ok

@@ -22,15 +22,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bench_frames.json")
 
-# name: (W, H, D, first seed, frames)   -- the names and seeds of bench.py's WORKLOADS
+# name: (W, H, D, first seed, frame indices)   -- the names and seeds of bench.py's WORKLOADS; frame f has seed first + f
 WORKLOADS = {
-    "kitti_1242x375_d128_p8": (1242, 375, 128, 0x5EED0002, 16),
-    "cone_450x375_d64_p8": (450, 375, 64, 0x5EED0001, 16),
-    "drivingstereo_1762x800_d192_p8": (1762, 800, 192, 0x5EED0005, 4),
-    "middlebury_2880x1988_d256_p8": (2880, 1988, 256, 0x5EED0003, 4),
-    "uhd_3840x2160_d128_p8": (3840, 2160, 128, 0x5EED0006, 8),
-    "uhd_3840x2160_d256_p8": (3840, 2160, 256, 0x5EED0007, 4),
+    "kitti_1242x375_d128_p8": (1242, 375, 128, 0x5EED0002, range(32)),          # BASELINE config 4: a batch of 32 frames
+    "cone_450x375_d64_p8": (450, 375, 64, 0x5EED0001, range(16)),
+    # BASELINE config 5 is a stream: bench.py pushes 256 distinct frames through and checks the first and the last four
+    "drivingstereo_1762x800_d192_p8": (1762, 800, 192, 0x5EED0005, list(range(4)) + list(range(252, 256))),
+    "middlebury_2880x1988_d256_p8": (2880, 1988, 256, 0x5EED0003, range(4)),
+    "uhd_3840x2160_d128_p8": (3840, 2160, 128, 0x5EED0006, range(8)),
+    "uhd_3840x2160_d256_p8": (3840, 2160, 256, 0x5EED0007, range(4)),
+    # BASELINE config 1 says "4 paths": not a mode of the reference (num_paths is never read).  The library's
+    # 4-path extension is defined by oracle/sgm_oracle.c alone, so THESE digests are oracle-made: "4-path parity unpinned by the
+    # reference" -- they pin the bench's timed frames to the CPU restatement, nothing more.
+    "cone_450x375_d64_p4": (450, 375, 64, 0x5EED0001, range(16)),
 }
+ORACLE_MADE = {"cone_450x375_d64_p4"}
 KEEP = ["disp_l", "disp_r", "after_lr", "after_speckle", "final"]
 
 
@@ -40,6 +46,15 @@ def one_frame(job):
     resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))   # SemiGlobalMatching.c:588-589
     import numpy as np
     from oracle.pyoracle import Oracle, Reference, default_option, sha
+    if name in ORACLE_MADE:
+        orc = Oracle()
+        orc.set_honor_num_paths(True)
+        left, right = orc.synth_pair(w, h, d, seed)
+        t0 = time.time()
+        st = orc.run(left, right, default_option(d, num_paths=4))
+        return name, seed, {"sha256": {n: sha(st[n]) for n in KEEP}, "sha256_inputs": {"left": sha(left), "right": sha(right)},
+                            "invalid_final": int(np.isinf(st["final"]).sum()), "made_by": "oracle/sgm_oracle.c (4 paths: no reference mode)",
+                            "reference_seconds": round(time.time() - t0, 1)}
     ref = Reference.for_shape(w, h, d)
     assert ref is not None, f"oracle/build_ref.sh {w} {h} {d} first"
     left, right = Oracle().synth_pair(w, h, d, seed)
@@ -51,7 +66,8 @@ def one_frame(job):
 
 
 def main():
-    names = sys.argv[1:] or list(WORKLOADS)
+    force = "--force" in sys.argv[1:]
+    names = [a for a in sys.argv[1:] if not a.startswith("--")] or list(WORKLOADS)
     doc = {"generator": "tests/golden/make_golden_bench.py", "workloads": {}}
     if os.path.exists(OUT):
         with open(OUT) as f:
@@ -59,9 +75,11 @@ def main():
     jobs = []
     for n in names:
         w, h, d, seed, frames = WORKLOADS[n]
-        doc["workloads"][n] = {"w": w, "h": h, "d": d, "first_seed": seed, "option": "main.c:48-65 with max_disparity = D",
-                               "frames": {}}
-        jobs += [(n, w, h, d, seed + k) for k in range(frames)]
+        old = {} if force else doc["workloads"].get(n, {}).get("frames", {})
+        doc["workloads"][n] = {"w": w, "h": h, "d": d, "first_seed": seed,
+                               "option": "main.c:48-65 with max_disparity = D" + (", num_paths = 4 honoured" if n in ORACLE_MADE else ""),
+                               "frames": dict(old)}
+        jobs += [(n, w, h, d, seed + k) for k in frames if str(seed + k) not in old]     # only what is missing (--force: all)
     jobs.sort(key=lambda j: -(j[1] * j[2] * j[3]))            # big frames first
     procs = int(os.environ.get("GOLDEN_PROCS", "3"))
     with mp.get_context("spawn").Pool(procs, maxtasksperchild=1) as pool:

@@ -9,6 +9,7 @@
  */
 #include "sgm_device.h"
 
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -27,7 +28,16 @@ int stub_log_arg(int i) { return (i >= 0 && i < g_n) ? g_log_arg[i] : -1; }
 /* the nth (0-based) call of launcher `name` from now on returns an error */
 void stub_fail_at(const char* name, int nth) { snprintf(g_fail_name, sizeof g_fail_name, "%s", name); g_fail_countdown = nth; }
 
+static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;     /* the tile-pipeline tests run ranks as threads */
+static int note_locked(const char* name, int arg);
 static int note(const char* name, int arg)
+{
+    pthread_mutex_lock(&g_mu);
+    const int rc = note_locked(name, arg);
+    pthread_mutex_unlock(&g_mu);
+    return rc;
+}
+static int note_locked(const char* name, int arg)
 {
     if (g_n < LOG_MAX) { snprintf(g_log[g_n], sizeof g_log[g_n], "%s", name); g_log_arg[g_n] = arg; ++g_n; }
     if (g_fail_countdown >= 0 && strcmp(name, g_fail_name) == 0 && g_fail_countdown-- == 0) {
@@ -41,6 +51,7 @@ int sgmd_device_count(void) { return 1; }
 int sgmd_device_is_gfx950(int o) { (void)o; return 1; }
 int sgmd_stream_create(int o, void** st) { (void)o; *st = malloc(8); return 0; }
 int sgmd_stream_create_cus(int o, void** st, int first, int count) { (void)o; *st = malloc(8); return note("stream_cus", first * 100 + count); }
+int sgmd_stream_create_prio(int o, void** st, int prio) { (void)o; *st = malloc(8); return note("stream_prio", prio); }
 int sgmd_device_cus(int o, int* per, int* xcds) { (void)o; *per = 32; *xcds = 8; return 0; }
 int sgmd_stream_destroy(int o, void* st) { (void)o; free(st); return 0; }
 int sgmd_stream_sync(int o, void* st) { (void)o; (void)st; return note("sync", 0); }
@@ -48,6 +59,9 @@ int sgmd_event_create(int o, void** e) { (void)o; *e = malloc(8); return 0; }
 void sgmd_event_destroy(int o, void* e) { (void)o; free(e); }
 int sgmd_event_record(int o, void* e, void* st) { (void)o; (void)e; (void)st; return note("event_record", 0); }
 int sgmd_stream_wait_event(int o, void* st, void* e) { (void)o; (void)st; (void)e; return note("wait_event", 0); }
+int sgmd_event_sync(int o, void* e) { (void)o; (void)e; return note("event_sync", 0); }
+int sgmd_set_device(int o) { (void)o; return 0; }
+int sgmd_mem_info(int o, size_t* f, size_t* t) { (void)o; *f = (size_t)200 << 30; *t = (size_t)288 << 30; return 0; }
 int sgmd_alloc(int o, void** p, size_t n)      /* logged with its size in KiB; nothing the tests do reads the bytes of a volume */
 { (void)o; *p = calloc(1, n > (1u << 20) ? (1u << 20) : (n ? n : 16)); note("alloc", (int)(n >> 10)); return *p ? 0 : 2; }
 int sgmd_free(int o, void* p) { (void)o; free(p); return 0; }

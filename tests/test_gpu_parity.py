@@ -209,6 +209,37 @@ def test_full_size_properties_kitti_batch(oracle):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("fast", ["1", "0"])
+@pytest.mark.parametrize("batch", [1, 3])
+def test_aggregation_step_families_at_their_penalty_limits(oracle, fast, batch, monkeypatch):
+    """The aggregation step comes in three families chosen from the penalties: FAST (max(P1, P2_init) <= 223: three-way packed
+    minimum through v_pk_minimum3_f16, no uint8 mask away from the left border), plain non-negative P1, generic (negative P1).
+    Penalties at and either side of the FAST limit, where C + bracket reaches exactly 255 / passes it, with the left-border
+    wraps (C = 127) in every case; SGM_AGG_FAST=0 runs the same cases on the plain step.  S and the final map against the oracle."""
+    import soc_project_stereo_matching_amd as S
+    from oracle.pyoracle import default_option
+    monkeypatch.setenv("SGM_AGG_FAST", fast)
+    i = S.SGMInstance(0, batch=batch)
+    i.keep_stages(True)
+    try:
+        for (p1, p2) in [(10, 150), (0, 223), (223, 0), (223, 223), (10, 224), (224, 10), (200, 231), (0, 0), (31488, 5), (32767, 32767)]:
+            for (w, h, dmin, dmax) in [(300, 40, 0, 128), (150, 25, 3, 93), (90, 33, 0, 64)]:
+                d = dmax - dmin
+                pairs = [oracle.synth_pair(w, h, d, 0xFA57 + 7 * p1 + p2 + w + j) for j in range(batch)]
+                opt = default_option(dmax, dmin, min_speckle_area=10, p1=p1, p2_init=p2)
+                assert i.reset(w, h, opt)
+                L = np.stack([p[0] for p in pairs]) if batch > 1 else pairs[0][0]
+                R = np.stack([p[1] for p in pairs]) if batch > 1 else pairs[0][1]
+                out = i.match(L, R)
+                for j, (l, r) in enumerate(pairs):
+                    want = oracle.run(l, r, opt)
+                    i.select_frame(j)
+                    assert_same(i.read_stage("aggr"), want["aggr"], f"S P1={p1} P2={p2} {w}x{h} d{dmin}-{dmax} frame {j}")
+                    assert_same(out[j] if batch > 1 else out, want["final"], f"final P1={p1} P2={p2} {w}x{h} frame {j}")
+    finally:
+        i.close()
+
+
 @pytest.mark.parametrize("hl", ["0", "32", "64"])
 @pytest.mark.parametrize("lanes", ["16", "8"])
 def test_lane_layouts_of_the_aggregation_kernel(oracle, hl, lanes, monkeypatch):

@@ -347,7 +347,7 @@ def test_platform_frame_entry_stage_order_and_errors(host):
     assert L.sgm_match_planes_async(s, *args)
     names = [n for n, _ in log(L, drop=keep)]
     assert names == ["h2d", "gray", "gray", "census", "aggregate", "sum_wta_lr", "event_record", "wait_event", "lrcheck", "speckle",
-                     "median", "event_record", "depth", "d2h", "event_record"]
+                     "median", "event_record", "depth", "event_record", "d2h"]          # "done" is recorded behind the depth kernel, not behind the copy
     L.stub_clear()
     assert L.sgm_disparity_to_depth(s, depth.ctypes.data, 960, 1000.0, 100.0, 0.0, depth.ctypes.data)
     assert [n for n, _ in log(L, drop=keep)] == ["wait_event", "depth"]
