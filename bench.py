@@ -235,30 +235,6 @@ def init_dist(args):
     return world, rank, local_rank, backend
 
 
-def init_dist(args):
-    import torch
-    import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    # one process per GPU; if the launcher already narrowed the visible devices to one per rank, that one is device 0
-    local_rank = local_rank if torch.cuda.device_count() > local_rank else 0
-    torch.cuda.set_device(local_rank)
-    # nccl (= RCCL) on a multi-GPU node; SGM_BENCH_BACKEND=gloo rehearses the same multi-process path on a box whose
-    # ranks share one GPU (RCCL refuses two ranks on one device)
-    backend = os.environ.get("SGM_BENCH_BACKEND", "nccl")
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=backend)
-    return world, rank, local_rank, backend
-
-
 def rooflines(workload, w, h, d, B, stage_ms, stage_min, launches, fused):
     """roofline objects of the two heavy kernels of a leg from its HIP-event stage times (None where a stage did not run)."""
     counters = load_counters(workload)

@@ -216,23 +216,34 @@ static __device__ __forceinline__ us2 pk_min_tree(const us2 (&v)[N])
         return m;
     }
 }
+// min over the lanes of a pixel of both halves of m, returned in BOTH halves of every lane (the packed operand the next step
+// subtracts): one VOP3P min with swapped halves, then the DPP all-reduce on the replicated word (u32 order = u16 order then)
+template <int LPP>
+static __device__ __forceinline__ unsigned row_allmin_pk(us2 m)
+{
+    unsigned r;
+    asm("v_pk_min_u16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(as_u(m)));
+    return row_allmin<LPP>(r);
+}
+// `mp` = min over d of the previous pixel's L in both halves (in and out); `sent` = two registers the caller initialises to
+// 0x00FF00FF and carries from step to step: the DPP shifts write into them, so the lanes without a source lane keep the 255
+// sentinels (ref :260-263) without a move per step.
 template <int DPL, bool PAD, int LPP, bool FAST = false>
 static __device__ __forceinline__ unsigned agg_step_nn(unsigned cl, const CensusVec<DPL>& cv, int lim, bool border,
-                                                       us2 (&Lp)[DPL / 2], unsigned min_prev, unsigned pen16, us2 p1v,
+                                                       us2 (&Lp)[DPL / 2], unsigned mp, unsigned pen16, us2 p1v,
                                                        const us2 (&padmask)[DPL / 2], bool first_lane, bool last_lane,
-                                                       CellVec<DPL>& packed_out)
+                                                       unsigned (&sent)[2], CellVec<DPL>& packed_out)
 {
     constexpr int NP = DPL / 2;
     const us2 p2v = as_p(pen16);                                    // both halves hold the penalty (32-bit table)
-    const unsigned mp = min_prev | (min_prev << 16);
     const unsigned p1u = as_u(p1v);
     unsigned from_left, from_right;
     if (LPP >= 32) {
-        from_left = dpp_mov<0x138 /* wave_shr:1 */>(0x00FF00FFu, as_u(Lp[NP - 1]));
-        from_right = dpp_mov<0x130 /* wave_shl:1 */>(0x00FF00FFu, as_u(Lp[0]));
+        from_left = sent[0] = dpp_mov<0x138 /* wave_shr:1 */>(sent[0], as_u(Lp[NP - 1]));
+        from_right = sent[1] = dpp_mov<0x130 /* wave_shl:1 */>(sent[1], as_u(Lp[0]));
     } else {
-        from_left = dpp_mov<DPP_ROW_SHR1>(0x00FF00FFu, as_u(Lp[NP - 1]));
-        from_right = dpp_mov<DPP_ROW_SHL1>(0x00FF00FFu, as_u(Lp[0]));
+        from_left = sent[0] = dpp_mov<DPP_ROW_SHR1>(sent[0], as_u(Lp[NP - 1]));
+        from_right = sent[1] = dpp_mov<DPP_ROW_SHL1>(sent[1], as_u(Lp[0]));
     }
     if (LPP != 16) {
         from_left = first_lane ? 0x00FF00FFu : from_left;
@@ -254,19 +265,19 @@ static __device__ __forceinline__ unsigned agg_step_nn(unsigned cl, const Census
         const unsigned lo = bcnt_acc(cl ^ cv.r[DPL - 1 - 2 * j], md[j]);              // C(2j) + md, high half = md's
         w[j] = shl16_add((unsigned)__popc(cl ^ cv.r[DPL - 2 - 2 * j]), lo);           // + C(2j+1) << 16
     }
-    if (border) {
+    if (border) {                                                                     // wave-uniform and rare: a real branch
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const unsigned msk = (2 * j > lim ? 0xFFFFu : 0u) | (2 * j + 1 > lim ? 0xFFFF0000u : 0u);
             w[j] = (w[j] & ~msk) | ((md[j] + 0x007F007Fu) & msk);
+            if constexpr (FAST) w[j] &= 0x00FF00FFu;                                  // only C = 127 can pass 255 (see above)
         }
     }
     us2 Ln[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         unsigned r = w[j];
-        if constexpr (FAST) { if (border) r &= 0x00FF00FFu; }                         // only C = 127 can pass 255 (see above)
-        else r &= 0x00FF00FFu;                                                        // uint8 truncation (Q7)
+        if constexpr (!FAST) r &= 0x00FF00FFu;                                        // uint8 truncation (Q7)
         if (PAD) r |= as_u(padmask[j]);
         Ln[j] = as_p(r);
     }
@@ -274,7 +285,7 @@ static __device__ __forceinline__ unsigned agg_step_nn(unsigned cl, const Census
 #pragma unroll
     for (int j = 0; j < NP; ++j) Lp[j] = Ln[j];
     pack_cells<DPL>(Ln, packed_out);
-    return row_allmin<LPP>(min(as_u(m) & 0xFFFFu, as_u(m) >> 16));
+    return row_allmin_pk<LPP>(m);
 }
 
 enum { AGG_H = 0, AGG_V = 1, AGG_D = 2 };
@@ -390,13 +401,19 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
             off = rowoff + __umul24(pcol, (unsigned)Dp) + lane_off;
         }
     };
+    // census words through 32-bit byte offsets from uniform bases (scalar base + VGPR offset addressing; a 64-bit address per
+    // load costs four VALU instructions per step): the right image's base is moved dmin + Dp words down into the slack in front
+    // of the allocation, so the lane's first word, p - back, is never negative
+    const unsigned cbias = (unsigned)(a.dmin + Dp - back);
+    const char* const crb = reinterpret_cast<const char*>(fr.census_r - (a.dmin + Dp));
+    const char* const clb_base = reinterpret_cast<const char*>(fr.census_l);
     auto fetch = [&](CensusVec<DPL>& cv, unsigned& cl, int& g) {
         if constexpr (VOL) {
             load_volume<DPL>(fr.cost + off, cv);
             cl = 0;
         } else {
-            load_census<DPL>(fr.census_r + ((long long)p - back), cv);
-            cl = fr.census_l[p];
+            load_census<DPL>(reinterpret_cast<const uint32_t*>(crb + (size_t)((p + cbias) << 2)), cv);
+            cl = *reinterpret_cast<const uint32_t*>(clb_base + (size_t)(p << 2));
         }
         g = fr.img[p];
     };
@@ -464,6 +481,8 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
         }
     }
     const us2 p1v = splat((unsigned)a.p1);
+    unsigned sent[2] = {0x00FF00FFu, 0x00FF00FFu};                         // agg_step_nn's carried sentinel registers
+    if constexpr (NN) min_prev |= min_prev << 16;                          // ... and its packed minimum
 
     // one step on ring slot u; `refill` = also fetch step k + PF into the slot
     auto step = [&](int u, bool refill) {
@@ -474,7 +493,7 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
         CellVec<DPL> packed;
         if constexpr (NN) {
             min_prev = agg_step_nn<DPL, PAD, LPP, NN == 2>(clb[u], cb[u], lim, __any(lim < DPL - 1) != 0, Lp, min_prev, lut32_s[dg], p1v,
-                                                  padmask, first_lane, last_lane, packed);
+                                                  padmask, first_lane, last_lane, sent, packed);
             if (refill) {                                                      // the slot's census words are consumed now
                 advance();
                 ob[u] = off;

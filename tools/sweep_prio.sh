@@ -7,14 +7,14 @@ mkdir -p "$(dirname "$out")"
 run() {
     local label=$1 inflight=$2 spec=$3
     local line
-    line=$(python bench.py --steps 60 --warmup 10 --in-flight "$inflight" --no-cpu-baseline --no-host-boundary ${spec:+--cu-split "$spec"} 2>>"$out.err" | tail -1)
+    line=$(python bench.py --steps 100 --warmup 20 --host-instances "$inflight" --legs sustained ${spec:+--cu-split "$spec"} 2>>"$out.err" | tail -1)
     python - "$label" "$inflight" "$spec" "$line" >> "$out" <<'PY'
 import json, sys
 label, inflight, spec, line = sys.argv[1:5]
 try:
     d = json.loads(line)
     st = d.get("stage_ms_per_batch_launch", {})
-    print(json.dumps({"label": label, "in_flight": int(inflight), "cu_split": spec, "fps": d["fps"], "ok": d["frames_verified"], "bad": d["frames_mismatched"],
+    print(json.dumps({"label": label, "in_flight": int(inflight), "cu_split": spec, "fps": d["sustained"]["fps"], "fps_steps": d["fps"], "ok": d["sustained"]["frames_verified"], "bad": d["sustained"]["frames_mismatched"] + d["frames_mismatched"],
                       "agg": st.get("aggregate"), "sum": st.get("sum"), "median": st.get("median"), "speckle": st.get("speckle")}))
 except Exception as e:
     print(json.dumps({"label": label, "error": repr(e), "raw": line[-300:]}))
