@@ -852,6 +852,10 @@ def main():
                          "what the pipeline schedule itself costs against --mode tiles with one rank; not a multi-GPU measurement")
     ap.add_argument("--tile-lead", type=int, default=int(os.environ.get("SGM_TILE_LEAD", "2")),
                     help="tiles mode: steps tile_begin of a frame is queued ahead of its first sweep (tiling.TilePipeline lead)")
+    ap.add_argument("--tile-host", default=os.environ.get("SGM_TILE_HOST", "c"), choices=["c", "python"],
+                    help="tiles mode: c = the library's own pipeline (include/sgm_tiles.h: schedule, slots, streams, events and the RCCL "
+                         "transport in C; default), python = tiling.TilePipeline driving the same C schedule with a Python engine over "
+                         "torch.distributed (what a gloo rehearsal on a one-GPU box needs)")
     ap.add_argument("--tile-rank-alone", default=None, metavar="r/N",
                     help="tiles mode: rank r of an N-rank pipeline alone on this GPU with the exchanges skipped: its time per frame "
                          "(a projection input for N GPUs, results are not produced)")
@@ -873,14 +877,14 @@ def main():
         # horizontal lines); on HIP's default of 4 hardware queues short kernels queue up behind those (measured, DESIGN.md
         # section 7: 1.9 -> 1.45 ms per frame for one rank of eight at 3840x2160).  Read by the runtime when it starts.
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-        from soc_project_stereo_matching_amd.tile_bench import run_tiles, run_tiles_in_process
+        import soc_project_stereo_matching_amd.tile_bench as tb
         args.workload = args.workload or "uhd_3840x2160_d128_p8"
+        python_host = args.tile_host == "python" or os.environ.get("SGM_BENCH_BACKEND", "nccl") != "nccl"
         if args.tile_rank_alone:
-            from soc_project_stereo_matching_amd.tile_bench import run_tile_rank_alone
-            return run_tile_rank_alone(args, args.tile_rank_alone, WORKLOADS)
+            return (tb.run_tile_rank_alone if python_host else tb.run_tile_rank_alone_c)(args, args.tile_rank_alone, WORKLOADS)
         if args.tile_ranks_in_process > 1:
-            return run_tiles_in_process(args, args.tile_ranks_in_process, WORKLOADS, golden_digests)
-        return run_tiles(args, init_dist, WORKLOADS, golden_digests)
+            return (tb.run_tiles_in_process if python_host else tb.run_tiles_in_process_c)(args, args.tile_ranks_in_process, WORKLOADS, golden_digests)
+        return (tb.run_tiles if python_host else tb.run_tiles_c)(args, init_dist, WORKLOADS, golden_digests)
     if args.cu_split or os.environ.get("SGM_BENCH_CU_SPLIT"):
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # up to three streams per instance in flight: no two of them on one hardware queue
     args.workload = args.workload or "kitti_1242x375_d128_p8"

@@ -326,9 +326,10 @@ static rccl_api g_rccl;
 static pthread_mutex_t g_rccl_mu = PTHREAD_MUTEX_INITIALIZER;
 enum { RCCL_UINT8 = 1 };                                              /* ncclUint8 */
 
+static bool g_rccl_forced;                                            /* SGM_RCCL_LIBRARY names the library: bind to nothing else */
 static void* rccl_sym(const char* name)
 {
-    void* p = dlsym(RTLD_DEFAULT, name);                              /* the copy the process already uses, if it is visible */
+    void* p = g_rccl_forced ? NULL : dlsym(RTLD_DEFAULT, name);       /* the copy the process already uses, if it is visible */
     if (!p && g_rccl.lib) p = dlsym(g_rccl.lib, name);
     return p;
 }
@@ -337,12 +338,16 @@ static bool rccl_bind(void)
     pthread_mutex_lock(&g_rccl_mu);
     bool ok = g_rccl.Send != NULL;
     if (!ok) {
-        if (!dlsym(RTLD_DEFAULT, "ncclSend")) {
-            const char* names[] = {getenv("SGM_RCCL_LIBRARY"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        const char* forced = getenv("SGM_RCCL_LIBRARY");
+        if (forced && *forced) {
+            g_rccl_forced = true;
+            if (!g_rccl.lib) g_rccl.lib = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        } else if (!dlsym(RTLD_DEFAULT, "ncclSend")) {
+            const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
             for (size_t i = 0; i < sizeof names / sizeof names[0] && !g_rccl.lib; ++i)
-                if (names[i] && *names[i]) g_rccl.lib = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD);      /* already loaded? */
+                g_rccl.lib = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD);                                  /* already loaded? */
             for (size_t i = 0; i < sizeof names / sizeof names[0] && !g_rccl.lib; ++i)
-                if (names[i] && *names[i]) g_rccl.lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
+                g_rccl.lib = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
         }
         *(void**)&g_rccl.GetUniqueId = rccl_sym("ncclGetUniqueId");
         *(void**)&g_rccl.CommInitRank = rccl_sym("ncclCommInitRank");

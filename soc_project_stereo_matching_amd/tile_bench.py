@@ -1,9 +1,13 @@
 """bench.py --mode tiles: every frame cut into WORLD_SIZE row tiles, one per GPU, frames in flight through the ranks.
 
-The schedule is tiling.TilePipeline (boundary hand-overs + row gather as one grouped exchange per step; speckle + median
-on the frame's owner rank).  A step is one frame; `value` = W*H*D*8*frames / elapsed (strong scaling: the same frames
-whatever the number of GPUs).  Backend nccl (= RCCL over xGMI) moves device tensors; SGM_BENCH_BACKEND=gloo stages them
-through the host, which is how the path is rehearsed on a box whose ranks share one GPU.
+The pipeline is the C library's (include/sgm_tiles.h: sgm_tiles_create / _submit / _finish -- the step schedule, the slots, their
+streams and events, the hand-over buffers and the RCCL transport are all C; this module submits frames and reads results).
+Boundary hand-overs + row gather are one grouped RCCL exchange per step; speckle + median run on the frame's owner rank.  A
+step is one frame; `value` = W*H*D*8*frames / elapsed (strong scaling: the same frames whatever the number of GPUs).
+torch.distributed carries the RCCL id to the ranks, the barriers and the timing all-reduce -- nothing on the data path.
+--tile-host python (or SGM_BENCH_BACKEND=gloo, which needs it) runs the same schedule with tiling.TilePipeline's Python engine
+instead: gloo stages the hand-overs through the host, which is how the multi-PROCESS path is rehearsed on a box whose ranks
+share one GPU (RCCL refuses two ranks on one device).
 
 Verification: the last frames every rank owns are snapshotted on the device inside the timed region and hashed afterwards
 against the digests the reference's own C produced for their seeds (tests/golden/bench_frames.json)."""
@@ -226,6 +230,181 @@ def run_tile_rank_alone(args, spec, WORKLOADS):
     eng.close()
     print(json.dumps({"tile_rank_alone": spec, "lead": lead, "slots": slots, "workload": args.workload, "rows": tile_rows(h, n)[r], "frames": args.steps * B,
                       "frames_per_step": B, "ms_per_frame": round(el / (args.steps * B) * 1e3, 4),
+                      "fps_if_this_rank_were_the_slowest": round(args.steps * B / el, 2),
+                      "note": "one rank's share of an N-rank pipeline alone on one GPU, exchanges skipped: a projection input, not a result"}),
+          flush=True)
+
+
+# ======================================================================================================================
+# the C host (include/sgm_tiles.h)
+# ======================================================================================================================
+
+def _c_pipeline(S, tiles, device, rank, world, w, h, opt, B, lead, in_flight, transport):
+    need = tiles.slots_needed(world, lead)
+    spare = max(1, (in_flight or 0) - need + 1)
+    slots = need + spare - 1
+    pipe = tiles.TilesPipeline(device, rank, world, w, h, opt, batch=B, lead=lead, spare=spare, throttle=slots, transport=transport)
+    return pipe, slots
+
+
+def _c_run(torch, pipe, get, n_steps):
+    for f in range(n_steps):
+        l, r = get(f)
+        if not pipe.submit(l.data_ptr(), r.data_ptr()):
+            raise RuntimeError(f"sgm_tiles_submit failed at frame {f}")
+    if not pipe.finish():                                            # queues the remaining steps and waits for every stream
+        raise RuntimeError("sgm_tiles_finish failed")
+
+
+def _c_snaps(ring, ring_frames, rank, world, n_steps, keep_last):
+    """The frames of the last `keep_last` steps this rank owns, as the result ring holds them after the stream has ended."""
+    mine = [f for f in range(max(0, n_steps - keep_last), n_steps) if f % world == rank][-ring_frames:]
+    return {f: ring[(f // world) % ring_frames] for f in mine}
+
+
+def run_tiles_c(args, init_dist, WORKLOADS, golden_digests):
+    import torch
+    import torch.distributed as dist
+    import soc_project_stereo_matching_amd as S
+    from . import tiles
+    from .tiling import tile_rows
+
+    world, rank, local_rank, backend = init_dist(args)
+    if world > 1 and backend != "nccl":
+        raise SystemExit("the C tile host moves device buffers over RCCL: use the nccl backend, or --tile-host python for a gloo rehearsal")
+    transport = None
+    if world > 1:
+        uid = [tiles.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)                       # 128 bytes, once: the only thing torch.distributed moves for the pipeline
+        transport = tiles.rccl_transport(uid[0], rank, world, local_rank)
+    w, h, d, seed = WORKLOADS[args.workload]
+    opt = S.default_option(d)
+    lead, B = args.tile_lead, max(1, args.batch or 1)
+    pipe, slots = _c_pipeline(S, tiles, local_rank, rank, world, w, h, opt, B, lead, args.in_flight, transport)
+    digests = golden_digests(args.workload)
+    get, seeds_of = _inputs(S, torch, w, h, d, seed, digests, B)
+    keep_last, ring_frames = 2 * world, 2
+    ring = torch.zeros((ring_frames, B, h, w), dtype=torch.float32, device="cuda")
+    pipe.result_ring(ring.data_ptr(), ring_frames)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    _c_run(torch, pipe, get, max(args.warmup, 1))                    # untimed: first-use allocations, RCCL connections
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _c_run(torch, pipe, get, args.steps)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    n_ok, n_bad, n_unpinned = _verify(_c_snaps(ring, ring_frames, rank, world, args.steps, keep_last), seeds_of, digests, B)
+    if world > 1:
+        t = torch.tensor([elapsed, float(n_ok), float(n_bad), float(n_unpinned)], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0].item())
+        n_ok, n_bad, n_unpinned = int(t[1].item()), int(t[2].item()), int(t[3].item())
+    pipe.close()
+    if transport is not None:
+        transport.close()
+    if rank == 0:
+        line = _line(args, B, w, h, d, world, tile_rows, slots, elapsed, n_ok, n_bad, n_unpinned, keep_last,
+                     f"{world} row tiles per frame; per step one grouped RCCL exchange per rank (ncclSend / ncclRecv from the C host): "
+                     "boundary path costs to both neighbours + finished rows to the frame's owner; speckle+median on the owner", world)
+        line["config"]["host"] = "C (sgm_tiles_submit / sgm_tiles_finish, include/sgm_tiles.h)"
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_tiles_in_process_c(args, ranks, WORKLOADS, golden_digests):
+    """`ranks` pipelines of the C host as THREADS of this process on ONE GPU, connected by the library's local transport (device
+    copies ordered by events stand in for the xGMI transfers).  Not a multi-GPU measurement: the schedule's own cost."""
+    import threading
+    import torch
+    import soc_project_stereo_matching_amd as S
+    from . import tiles
+    from .tiling import tile_rows
+
+    w, h, d, seed = WORKLOADS[args.workload]
+    opt = S.default_option(d)
+    lead, B = args.tile_lead, max(1, args.batch or 1)
+    digests = golden_digests(args.workload)
+    get, seeds_of = _inputs(S, torch, w, h, d, seed, digests, B)
+    keep_last, ring_frames = 2 * ranks, 2
+    group = tiles.LocalGroup(ranks, 0)
+    snaps, errors, times, slots_of = {}, [], [0.0, 0.0], [0] * ranks
+    bar = threading.Barrier(ranks)
+
+    def rank_main(r):
+        try:
+            tr = group.transport(r)
+            pipe, slots_of[r] = _c_pipeline(S, tiles, 0, r, ranks, w, h, opt, B, lead, args.in_flight, tr)
+            ring = torch.zeros((ring_frames, B, h, w), dtype=torch.float32, device="cuda:0")
+            pipe.result_ring(ring.data_ptr(), ring_frames)
+            _c_run(torch, pipe, get, max(args.warmup, 1))
+            torch.cuda.synchronize()
+            bar.wait()
+            if r == 0:
+                times[0] = time.perf_counter()
+            _c_run(torch, pipe, get, args.steps)
+            bar.wait()
+            if r == 0:
+                times[1] = time.perf_counter()
+            snaps.update({f: m.clone() for f, m in _c_snaps(ring, ring_frames, r, ranks, args.steps, keep_last).items()})
+            pipe.close()
+            tr.close()
+        except Exception as exc:                                      # noqa: BLE001
+            errors.append((r, repr(exc)))
+            bar.abort()
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(ranks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    group.close()
+    if errors:
+        raise RuntimeError(f"in-process tile ranks failed: {errors}")
+    elapsed = times[1] - times[0]
+    n_ok, n_bad, n_unpinned = _verify(snaps, seeds_of, digests, B)
+    line = _line(args, B, w, h, d, ranks, tile_rows, slots_of[0], elapsed, n_ok, n_bad, n_unpinned, keep_last,
+                 f"{ranks} row tiles per frame driven by {ranks} threads of one process on ONE GPU (sgm_tiles_local transport: device "
+                 "copies stand in for xGMI): the schedule's own cost, not a multi-GPU measurement", 1)
+    line["config"]["mode"] = f"tiles, {ranks} in-process ranks on one GPU"
+    line["config"]["host"] = "C (sgm_tiles_submit / sgm_tiles_finish, include/sgm_tiles.h)"
+    print(json.dumps(line), flush=True)
+
+
+def run_tile_rank_alone_c(args, spec, WORKLOADS):
+    """`spec` = "r/N": rank r of an N-rank pipeline of the C host alone on this GPU, its exchanges moving nothing (tiles.NullTransport).
+    A projection input (1 / max over the ranks = the rate N GPUs could reach with the exchanges fully hidden), NOT a multi-GPU
+    measurement; there are no results to verify."""
+    import torch
+    import soc_project_stereo_matching_amd as S
+    from . import tiles
+    from .tiling import tile_rows
+    r, n = (int(v) for v in spec.split("/"))
+    w, h, d, seed = WORKLOADS[args.workload]
+    opt = S.default_option(d)
+    lead, B = args.tile_lead, max(1, args.batch or 1)
+    null = tiles.NullTransport()
+    pipe, slots = _c_pipeline(S, tiles, 0, r, n, w, h, opt, B, lead, args.in_flight, null.struct)
+    get, _ = _inputs(S, torch, w, h, d, seed, None, B)
+    _c_run(torch, pipe, get, max(args.warmup, 1))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _c_run(torch, pipe, get, args.steps)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    pipe.close()
+    print(json.dumps({"tile_rank_alone": spec, "host": "C", "lead": lead, "slots": slots, "workload": args.workload, "rows": tile_rows(h, n)[r],
+                      "frames": args.steps * B, "frames_per_step": B, "ms_per_frame": round(el / (args.steps * B) * 1e3, 4),
                       "fps_if_this_rank_were_the_slowest": round(args.steps * B / el, 2),
                       "note": "one rank's share of an N-rank pipeline alone on one GPU, exchanges skipped: a projection input, not a result"}),
           flush=True)

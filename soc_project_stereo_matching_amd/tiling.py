@@ -379,7 +379,8 @@ class TilePipeline:
     def slots_needed(world: int, lead: int = 0) -> int:
         """A frame occupies its slot from tile_begin (step f) to the post pass (step f + lead + world + 1; with one rank there is
         no row gather to wait for and the post pass follows tile_finish in step f + lead)."""
-        return (world + 3 if world > 1 else 2) + lead
+        from . import tiles
+        return tiles.slots_needed(world, lead)
 
     def __init__(self, engine: SlotEngine, rank: int, world: int, height: int, dist=None, lead: int = 0):
         if lead < 0:
@@ -390,66 +391,45 @@ class TilePipeline:
         self.rows = tile_rows(height, world)
 
     def run(self, n_frames: int, get_frame, on_result=None, throttle: int = 0):
-        """`lead`: tile_begin of a frame is queued `lead` steps before its first sweep can start.  tile_begin is the longest serial
+        """Runs the stream.  The step order is the C library's (sgm_tile_step, csrc/sgm_tile_sched.c -- the same function the
+        device pipeline of sgm_tiles.c runs); this method only adapts a SlotEngine to its engine table.
+
+        `lead`: tile_begin of a frame is queued `lead` steps before its first sweep can start.  tile_begin is the longest serial
         chain of a tile (its horizontal lines: W - 1 dependent steps, whatever the number of ranks) and uses a fraction of the
         GPU; queued in the step of the first sweep (lead 0) it is on the critical path of rank 0 and rank N-1 -- every step then
         lasts tile_begin + sweep -- with a lead it runs beside the sweeps of the frames before."""
+        from . import tiles
         e, r, N, F, K = self.e, self.rank, self.world, n_frames, self.lead
         R = e.slots
-        slot = lambda f: f % R                                       # noqa: E731
-        valid = lambda f: 0 <= f < F                                 # noqa: E731
-        lag = max(r, N - 1 - r)
+
+        def begin(slot, frame):
+            l, rt = get_frame(frame)
+            e.begin(slot, l, rt)
+
+        def exchange(ops, slots):
+            # boundary operations first, then the row gather, as the schedule lists them (neighbouring ranks list the
+            # operations between them in the same order)
+            py = []
+            for o in ops:
+                kind = "send" if o.kind == tiles.XOP_SEND else "recv"
+                if o.buf == tiles.XBUF_BOUNDARY:
+                    py.append((kind, e.boundary(o.slot, bool(o.forward), bool(o.incoming)), o.peer))
+                else:
+                    py += [(kind, v, o.peer) for v in e.row_views(o.slot, o.row_begin, o.row_end)]
+            e.exchange(self.dist, py, slots)
+
+        def post(slot, frame):
+            e.post(slot)
+            if on_result is not None:
+                on_result(frame, e.frame_map(slot), e.done(slot))
+
+        eng = tiles.PyEngine(begin, e.import_boundary, e.sweep, e.export_boundary, exchange, e.finish, post)
         step_done = []
-        for step in range(F + N + 2 + K):
+        for step in range(tiles.steps_total(F, N, K)):
             if throttle and step >= throttle and step_done[step - throttle] is not None:
                 step_done[step - throttle].synchronize()             # bound the host's run-ahead
-            touched = set()
-            if valid(step):
-                l, rt = get_frame(step)
-                e.begin(slot(step), l, rt)
-            s = step - K                                             # the schedule of the header comment, K steps behind the begins
-            f, g = s - r, s - (N - 1 - r)
-            for forward, fr in ((True, f), (False, g)):
-                if not valid(fr):
-                    continue
-                first = (r == 0) if forward else (r == N - 1)
-                last = (r == N - 1) if forward else (r == 0)
-                if not first:
-                    e.import_boundary(slot(fr), forward)
-                e.sweep(slot(fr), forward)
-                if not last:
-                    e.export_boundary(slot(fr), forward)
-            # ---- the exchange between step s and s + 1, queued BEFORE this step's tile_finish: it waits for what the slots
-            #      have queued so far, and the next step's sweeps wait for it -- the cost sum of a frame must not sit on that
-            #      chain.  Boundary operations first, then the row gather (neighbouring ranks list the operations between them
-            #      in the same order); the gather is of the frame every rank finished in an EARLIER step (s - N).
-            ops = []
-            if N > 1:
-                if valid(f) and r < N - 1:
-                    ops.append(("send", e.boundary(slot(f), True, False), r + 1)); touched.add(slot(f))
-                if valid(s + 1 - r) and r > 0:
-                    ops.append(("recv", e.boundary(slot(s + 1 - r), True, True), r - 1)); touched.add(slot(s + 1 - r))
-                if valid(g) and r > 0:
-                    ops.append(("send", e.boundary(slot(g), False, False), r - 1)); touched.add(slot(g))
-                if valid(s + 1 - (N - 1 - r)) and r < N - 1:
-                    ops.append(("recv", e.boundary(slot(s + 1 - (N - 1 - r)), False, True), r + 1)); touched.add(slot(s + 1 - (N - 1 - r)))
-                h = s - N
-                if valid(h):
-                    owner = h % N
-                    touched.add(slot(h))
-                    if r != owner:
-                        ops += [("send", v, owner) for v in e.row_views(slot(h), *self.rows[r])]
-                    else:
-                        ops += [("recv", v, k) for k in range(N) if k != r for v in e.row_views(slot(h), *self.rows[k])]
-                e.exchange(self.dist, ops, sorted(touched))
-            if valid(s - lag):
-                e.finish(slot(s - lag))
-            p = s - N - 1 if N > 1 else s                            # one rank: nothing to gather, post follows finish
-            if valid(p) and p % N == r:
-                e.post(slot(p))
-                if on_result is not None:
-                    on_result(p, e.frame_map(slot(p)), e.done(slot(p)))
-            step_done.append(e.done(slot(step)) if throttle else None)
+            eng.step(r, N, self.h, R, K, step, F)
+            step_done.append(e.done(step % R) if throttle else None)
         e.drain()
 
 

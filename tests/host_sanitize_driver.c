@@ -3,6 +3,9 @@
  * nothing) under AddressSanitizer / UBSan -- buffer sizes, staging copies, table uploads, tile hand-over offsets and the
  * lifetime of everything the host allocates.  Results are not checked (there are none). */
 #include "../include/sgm_mi355x.h"
+#include "../include/sgm_tiles.h"
+
+#include <pthread.h>
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -18,6 +21,57 @@ static SGMOption options(int d, int dmin)
     o.is_check_lr = true; o.lrcheck_thres = 1.0f; o.is_check_unique = true; o.uniqueness_ratio = 0.99;
     o.is_remove_speckles = true; o.min_speckle_area = 20; o.p1 = 10; o.p2_init = 150;
     return o;
+}
+
+/* the multi-GPU host (csrc/sgm_tiles.c) with ranks as threads: the stub device's toy compute touches every plane cell, hand-over
+ * buffer and map the pipeline allocates, so the sanitizer sees the offsets of the real data flow */
+void stub_toy_compute(int on);
+typedef struct { int rank, world, batch, lead; sgm_tiles_local* group; const uint8_t* img; float* ring; int ring_frames; int ok; } rank_arg;
+static void* rank_main(void* p)
+{
+    rank_arg* a = (rank_arg*)p;
+    const int W = 12, H = 13;
+    SGMOption o = options(16, 0);
+    sgm_tiles_transport tr;
+    memset(&tr, 0, sizeof tr);
+    if (a->world > 1 && !sgm_tiles_local_transport(a->group, a->rank, &tr)) return NULL;
+    sgm_tiles* t = sgm_tiles_create(0, a->rank, a->world, (uint16_t)W, (uint16_t)H, &o, a->batch, a->lead, 1, 2, a->world > 1 ? &tr : NULL);
+    if (!t) return NULL;
+    sgm_tiles_result_ring(t, a->ring, a->ring_frames);
+    int ok = 1;
+    for (int k = 0; ok && k < 2 * a->world + 3; ++k) ok = sgm_tiles_submit(t, a->img, a->img, NULL);
+    ok = ok && sgm_tiles_finish(t);
+    /* a second stream on the same pipeline */
+    for (int k = 0; ok && k < 2; ++k) ok = sgm_tiles_submit(t, a->img, a->img, NULL);
+    ok = ok && sgm_tiles_finish(t);
+    sgm_tiles_destroy(t);
+    if (tr.destroy) tr.destroy(tr.ctx);
+    a->ok = ok;
+    return NULL;
+}
+static int tiles_pipeline(const uint8_t* img)
+{
+    stub_toy_compute(1);
+    for (int world = 1; world <= 4; ++world)
+        for (int batch = 1; batch <= 2; ++batch) {
+            sgm_tiles_local* g = world > 1 ? sgm_tiles_local_group(world, 0) : NULL;
+            rank_arg a[4];
+            pthread_t th[4];
+            const int ring_frames = 3;
+            for (int r = 0; r < world; ++r) {
+                a[r] = (rank_arg){r, world, batch, batch == 1 ? 2 : 0, g, img, NULL, ring_frames, 0};
+                a[r].ring = (float*)calloc((size_t)ring_frames * batch * 12 * 13, sizeof(float));
+                CHECK(a[r].ring && pthread_create(&th[r], NULL, rank_main, &a[r]) == 0);
+            }
+            for (int r = 0; r < world; ++r) {
+                pthread_join(th[r], NULL);
+                free(a[r].ring);
+                CHECK(a[r].ok);
+            }
+            sgm_tiles_local_destroy(g);
+        }
+    stub_toy_compute(0);
+    return 0;
 }
 
 int main(void)
@@ -97,6 +151,8 @@ int main(void)
                 CHECK(sgm_set_rows(s, 0, 0) && sgm_reset(s, (uint16_t)w, (uint16_t)h, &o) && sgm_match(s, img, img, out));
                 sgm_destroy(s);
             }
+
+    CHECK(tiles_pipeline(img) == 0);
 
     free(img); free(out); free(buf); free(stage);
     printf("host_sanitize_driver ok\n");

@@ -91,6 +91,46 @@ void sgmd_timer_destroy(int o, void* t) { (void)o; free(t); }
 int sgmd_timer_mark(int o, void* t, void* st, int i) { (void)o; (void)t; (void)st; (void)i; return 0; }
 int sgmd_timer_elapsed(int o, void* t, int a, int b, float* ms) { (void)o; (void)t; (void)a; (void)b; *ms = 0.f; return 0; }
 
+/* ---- toy compute (tests/test_tiles_c.py): with stub_toy_compute(1) the aggregation, the cost sum and the post pass compute a
+ * small recurrence with the data dependencies of SGM's vertical / diagonal paths on byte 0 of every cell, so that the row-tile
+ * pipeline (csrc/sgm_tiles.c) can be checked END TO END on the CPU -- hand-over routing, slot reuse, row gather, batches -- against
+ * the same recurrence on the whole frame.  Only for frames whose planes fit the allocator's cap. ---- */
+static int g_toy;
+void stub_toy_compute(int on) { g_toy = on; }
+static unsigned char* toy_cell(void* planes, size_t pb, const sgmd_geom* g, int f, int d, int y, int x)
+{ return (unsigned char*)planes + ((size_t)f * 8 + (size_t)d) * pb + ((size_t)y * g->W + x) * g->Dp; }
+static void toy_aggregate(const sgmd_geom* g, const sgmd_paths* p, const unsigned char* img, void* planes, size_t pb)
+{
+    for (int f = 0; f < g->B; ++f)
+        for (int d = 0; d < p->ndirs; ++d) {
+            if (!((p->dir_mask >> d) & 1)) continue;
+            const int dy = p->dy[d], dx = p->dx[d];
+            if (dy == 0) {                                           /* row-local */
+                for (int y = g->row_begin; y < g->row_end; ++y)
+                    for (int x = 0; x < g->W; ++x) *toy_cell(planes, pb, g, f, d, y, x) = (unsigned char)(3 * d + img[((size_t)f * g->H + y) * g->W + x]);
+                continue;
+            }
+            for (int k = 0; k < g->row_end - g->row_begin; ++k) {   /* along y, reading the row before (the imported one at a tile edge) */
+                const int y = dy > 0 ? g->row_begin + k : g->row_end - 1 - k, py = y - dy;
+                for (int x = 0; x < g->W; ++x) {
+                    const int px = ((x - dx) % g->W + g->W) % g->W;     /* wraps like the reference's diagonals */
+                    const unsigned prev = (py >= 0 && py < g->H) ? *toy_cell(planes, pb, g, f, d, py, px) : 0u;
+                    *toy_cell(planes, pb, g, f, d, y, x) = (unsigned char)(prev * 5u + img[((size_t)f * g->H + y) * g->W + x] + (unsigned)d);
+                }
+            }
+        }
+}
+static void toy_sum(const sgmd_geom* g, int nd, const void* planes, size_t pb, void* disp)
+{
+    for (int f = 0; f < g->B; ++f)
+        for (int y = g->row_begin; y < g->row_end; ++y)
+            for (int x = 0; x < g->W; ++x) {
+                unsigned s = 0;
+                for (int d = 0; d < nd; ++d) s += *toy_cell((void*)planes, pb, g, f, d, y, x);
+                ((float*)disp)[((size_t)f * g->H + y) * g->W + x] = (float)s;
+            }
+}
+
 int sgmd_census(int o, void* st, const sgmd_geom* g, const void* l, const void* r, void* cl, void* cr, const void* need, int keep)
 { (void)o; (void)st; (void)l; (void)r; (void)cl; (void)cr; (void)need; return note("census", g->B | (keep << 16)); }
 void sgmd_census_blocks(const sgmd_geom* g, int* bx, int* by) { *bx = (g->W + 63) / 64; *by = (g->H + 15) / 16; }
@@ -108,7 +148,7 @@ int sgmd_lrcheck_right(int o, void* st, const sgmd_geom* g, const void* dr, cons
 size_t sgmd_census_slack(const sgmd_geom* g) { return ((size_t)g->dmin + g->Dp + 8) * 4; }
 int sgmd_aggregate(int o, void* st, const sgmd_geom* g, const sgmd_paths* p, const void* img, const void* cl, const void* cr,
                    const void* lut, void* planes, size_t pb, void* ex)
-{ (void)o; (void)st; (void)g; (void)img; (void)cl; (void)cr; (void)lut; (void)planes; (void)pb; (void)ex; return note("aggregate", p->dir_mask); }
+{ (void)o; (void)st; (void)cl; (void)cr; (void)lut; (void)ex; if (g_toy) toy_aggregate(g, p, (const unsigned char*)img, planes, pb); return note("aggregate", p->dir_mask); }
 int sgmd_sum_wta(int o, void* st, const sgmd_geom* g, int nd, const void* pl, size_t pb, const void* ex, const void* re,
                  const void* rc, int cap, int accumulate, void* S, int cu, float omr, void* dl)
 { (void)o; (void)st; (void)g; (void)nd; (void)pl; (void)pb; (void)ex; (void)re; (void)rc; (void)cap; (void)S; (void)cu; (void)omr; (void)dl;
@@ -116,14 +156,17 @@ int sgmd_sum_wta(int o, void* st, const sgmd_geom* g, int nd, const void* pl, si
 int sgmd_sum_wta_lr_supported(const sgmd_geom* g, int cap) { (void)cap; return g->Dp <= 256; }
 int sgmd_sum_wta_lr(int o, void* st, const sgmd_geom* g, int nd, const void* pl, size_t pb, const void* ex, const void* re,
                     const void* rc, int cap, int accumulate, int store_S, int do_right, void* S, int cu, float omr, void* dl, void* dr)
-{ (void)o; (void)st; (void)g; (void)nd; (void)pl; (void)pb; (void)ex; (void)re; (void)rc; (void)cap; (void)do_right; (void)S; (void)cu; (void)omr; (void)dl; (void)dr;
+{ (void)o; (void)st; (void)ex; (void)re; (void)rc; (void)cap; (void)do_right; (void)S; (void)cu; (void)omr; (void)dr;
+  if (g_toy) toy_sum(g, nd, pl, pb, dl);
   return note("sum_wta_lr", accumulate | (store_S << 1)); }
 int sgmd_wta_right(int o, void* st, const sgmd_geom* g, const void* S, int cu, float omr, void* dr)
 { (void)o; (void)st; (void)g; (void)S; (void)cu; (void)omr; (void)dr; return note("wta_right", 0); }
 int sgmd_lrcheck(int o, void* st, const sgmd_geom* g, void* dl, const void* dr, float th)
 { (void)o; (void)st; (void)g; (void)dl; (void)dr; (void)th; return note("lrcheck", 0); }
 int sgmd_speckle(int o, void* st, const sgmd_geom* g, void* d, float diff, unsigned area, void* a, void* b, void* c)
-{ (void)o; (void)st; (void)g; (void)d; (void)diff; (void)a; (void)b; (void)c; return note("speckle", (int)area); }
+{ (void)o; (void)st; (void)diff; (void)a; (void)b; (void)c;
+  if (g_toy) for (size_t i = 0; i < (size_t)g->B * g->W * g->H; ++i) ((float*)d)[i] += 1000.0f;       /* whole-frame pass, once per frame */
+  return note("speckle", (int)area); }
 size_t sgmd_median_scratch_bytes(const sgmd_geom* g) { return (size_t)g->W * g->H * 4; }
 static int g_median_stall;
 void stub_median_stall(int on) { g_median_stall = on; }      /* the next median launches report a band that gave up waiting */

@@ -335,3 +335,145 @@ def test_pipeline_of_batched_tiles_ranks_as_threads(oracle, case):
     finally:
         oracle.set_honor_num_paths(False)
         oracle.set_reference_view(False)
+
+
+# ======================================================================================================================
+# the C host of the pipeline (include/sgm_tiles.h): sgm_tiles_create / _submit / _finish, local and RCCL transports
+# ======================================================================================================================
+
+def _c_ranks(oracle, w, h, d, world, batch, lead, n_steps, opt=None, in_flight=0):
+    """`world` C pipelines as threads on the one GPU (world == 1: no transport); returns ({step: [batch][H][W] map}, wanted)."""
+    import threading
+    import torch
+    from oracle.pyoracle import default_option
+    from soc_project_stereo_matching_amd import tiles
+    opt = opt or default_option(d)
+    pairs = [[oracle.synth_pair(w, h, d, 0xC711E + 97 * k + j) for j in range(batch)] for k in range(n_steps)]
+    dev = [(torch.from_numpy(np.stack([p[0] for p in ps])).cuda(), torch.from_numpy(np.stack([p[1] for p in ps])).cuda()) for ps in pairs]
+    torch.cuda.synchronize()
+    ring_frames = (n_steps + world - 1) // world
+    rings = [torch.full((ring_frames, batch, h, w), -7.0, dtype=torch.float32, device="cuda") for _ in range(world)]
+    group = tiles.LocalGroup(world, 0) if world > 1 else None
+    errors = []
+
+    def rank_main(r):
+        try:
+            tr = group.transport(r) if group else None
+            need = tiles.slots_needed(world, lead)
+            pipe = tiles.TilesPipeline(0, r, world, w, h, opt, batch=batch, lead=lead, spare=max(1, in_flight - need + 1),
+                                       throttle=need, transport=tr)
+            assert pipe.info()[:2] == tiles.tile_rows(h, world, r)
+            pipe.result_ring(rings[r].data_ptr(), ring_frames)
+            for k in range(n_steps):
+                assert pipe.submit(dev[k][0].data_ptr(), dev[k][1].data_ptr()), f"submit {k}"
+            assert pipe.finish()
+            pipe.close()
+            if tr is not None:
+                tr.close()
+        except BaseException as e:                                    # noqa: BLE001
+            errors.append((r, repr(e)))
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(600)
+    assert not any(t.is_alive() for t in th), "a rank is stuck"
+    if group:
+        group.close()
+    assert not errors, errors
+    got = {k: rings[k % world][(k // world) % ring_frames].cpu().numpy() for k in range(n_steps)}
+    want = {k: [oracle.run(l, r, opt)["final"] for l, r in pairs[k]] for k in range(n_steps)}
+    return got, want
+
+
+@pytest.mark.parametrize("case", [
+    # W, H, D, ranks, batch, lead, frames
+    (300, 70, 48, 1, 1, 2, 5),
+    (300, 70, 48, 2, 1, 0, 6),
+    (160, 50, 32, 3, 2, 2, 7),
+    (37, 61, 8, 4, 1, 1, 9),                       # W < H
+    (130, 47, 48, 5, 1, 3, 11),
+], ids=lambda c: f"{c[0]}x{c[1]}_d{c[2]}_n{c[3]}_b{c[4]}_lead{c[5]}")
+def test_c_pipeline_ranks_as_threads(oracle, case):
+    """The library's own pipeline, N ranks as threads connected by its local transport: every frame of the stream -- more frames
+    than slots, so slots and hand-over buffers are reused -- must be the single-GPU result bit for bit."""
+    w, h, d, world, batch, lead, n = case
+    got, want = _c_ranks(oracle, w, h, d, world, batch, lead, n)
+    for k in range(n):
+        for b in range(batch):
+            assert_same(got[k][b], want[k][b], f"frame {k}.{b}")
+
+
+def test_c_pipeline_kitti_in_eight_tiles_matches_the_reference_digest():
+    """BASELINE.json configs[3]: KITTI frames in 8 row tiles through the C pipeline (8 threads standing in for 8 GPUs); the maps
+    must hash to the digests the REFERENCE produced (tests/golden/bench_frames.json holds them for the bench's seeds)."""
+    import json
+    import threading
+    import torch
+    import soc_project_stereo_matching_amd as S
+    from oracle.pyoracle import sha
+    from soc_project_stereo_matching_amd import tiles
+    with open(os.path.join(ROOT, "tests", "golden", "bench_frames.json")) as f:
+        wl = json.load(f)["workloads"]["kitti_1242x375_d128_p8"]
+    w, h, d, seed0 = 1242, 375, 128, 0x5EED0002
+    world, n_steps, lead = 8, 10, 2
+    opt = S.default_option(d)
+    dev = []
+    for k in range(n_steps):
+        l, r = S.synth_pair(w, h, d, seed0 + k)
+        dev.append((torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()))
+    torch.cuda.synchronize()
+    ring_frames = 2
+    rings = [torch.zeros((ring_frames, 1, h, w), dtype=torch.float32, device="cuda") for _ in range(world)]
+    group = tiles.LocalGroup(world, 0)
+    errors = []
+
+    def rank_main(r):
+        try:
+            tr = group.transport(r)
+            pipe = tiles.TilesPipeline(0, r, world, w, h, opt, batch=1, lead=lead, throttle=4, transport=tr)
+            pipe.result_ring(rings[r].data_ptr(), ring_frames)
+            for k in range(n_steps):
+                assert pipe.submit(dev[k][0].data_ptr(), dev[k][1].data_ptr())
+            assert pipe.finish()
+            pipe.close()
+            tr.close()
+        except BaseException as e:                                    # noqa: BLE001
+            errors.append((r, repr(e)))
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(600)
+    group.close()
+    assert not errors, errors
+    for k in range(n_steps):
+        assert sha(rings[k % world][(k // world) % ring_frames][0].cpu().numpy()) == wl["frames"][str(seed0 + k)]["sha256"]["final"], k
+
+
+def test_c_rccl_transport_on_one_gpu():
+    """The product transport of the C host with the REAL librccl, in the only form one GPU allows: a communicator of one rank
+    whose grouped sends meet its own receives (dlopen / ncclCommInitRank / ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on
+    a stream of the library).  Two ranks on two GPUs are the driver's multi-GPU run."""
+    import torch
+    from soc_project_stereo_matching_amd import tiles
+    uid = tiles.rccl_unique_id()
+    assert len(uid) == tiles.ID_BYTES and not uid.startswith(b"stub-rccl")
+    tr = tiles.rccl_transport(uid, 0, 1, 0)
+    st = torch.cuda.Stream()
+    a = torch.arange(1 << 20, dtype=torch.uint8, device="cuda")
+    b = torch.arange(4096, dtype=torch.float32, device="cuda")
+    ra, rb = torch.zeros_like(a), torch.zeros_like(b)
+    st.wait_stream(torch.cuda.current_stream())
+    sp = st.cuda_stream
+    for _ in range(3):                                                # the same communicator, several groups
+        ra.zero_(); rb.zero_()
+        st.wait_stream(torch.cuda.current_stream())
+        assert tr.group_start(tr.ctx) == 0
+        assert tr.send(tr.ctx, a.data_ptr(), a.numel(), 0, sp) == 0 and tr.recv(tr.ctx, ra.data_ptr(), ra.numel(), 0, sp) == 0
+        assert tr.send(tr.ctx, b.data_ptr(), b.numel() * 4, 0, sp) == 0 and tr.recv(tr.ctx, rb.data_ptr(), rb.numel() * 4, 0, sp) == 0
+        assert tr.group_end(tr.ctx) == 0
+        st.synchronize()
+        assert torch.equal(a, ra) and torch.equal(b, rb)
+    tr.close()

@@ -1,4 +1,4 @@
-"""The product's C host (csrc/sgm_host.c) is AddressSanitizer / UBSan clean when driven through every entry-point family
+"""The product's C host (csrc/sgm_host.c, and the multi-GPU host csrc/sgm_tiles.c + sgm_tile_sched.c with ranks as threads) is AddressSanitizer / UBSan clean when driven through every entry-point family
 with the stub device layer (tests/stub_device.c) -- no GPU; sanitizers are only available for the CPU build."""
 import os
 import shutil
@@ -14,9 +14,10 @@ CSRC = os.path.join(ROOT, "soc_project_stereo_matching_amd", "csrc")
 @pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc not available")
 def test_host_is_asan_ubsan_clean(tmp_path):
     exe = str(tmp_path / "host_sanitize_driver")
-    subprocess.check_call(["gcc", "-O1", "-g", "-std=c11", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I", CSRC,
+    subprocess.check_call(["gcc", "-O1", "-g", "-std=c11", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-D_GNU_SOURCE", "-I", CSRC,
                            "-o", exe, os.path.join(ROOT, "tests", "host_sanitize_driver.c"), os.path.join(CSRC, "sgm_host.c"),
-                           os.path.join(ROOT, "tests", "stub_device.c"), "-lm"])
+                           os.path.join(CSRC, "sgm_tile_sched.c"), os.path.join(CSRC, "sgm_tiles.c"),
+                           os.path.join(ROOT, "tests", "stub_device.c"), "-lm", "-ldl", "-lpthread"])
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1")
     env.pop("LD_PRELOAD", None)
     out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=120)
