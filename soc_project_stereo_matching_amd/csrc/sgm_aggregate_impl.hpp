@@ -4,6 +4,9 @@
 #ifndef SGM_AGG_PF
 #define SGM_AGG_PF 2      // steps of census words / grey values a wave keeps in flight (8- and 16-lane lines); 3 measured no faster
 #endif
+#ifndef SGM_AGG_PF_HL
+#define SGM_AGG_PF_HL 4   // the same for the 32- / 64-lane horizontal lines of a single frame (the launch's critical chain)
+#endif
 
 // ============================================================================================
 // path aggregation  (ref :198-372)
@@ -304,7 +307,7 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
                                                    const unsigned* lut32_s, int dir, int grp)
 {
     constexpr int NP = DPL / 2;
-    constexpr int PF = (LPP >= 32) ? 4 : SGM_AGG_PF;                              // prefetch depth (steps): 2 keeps the 8-lines-per-wave kernel at 8 waves/SIMD; the latency-critical 32-lane lines look further ahead
+    constexpr int PF = (LPP >= 32) ? SGM_AGG_PF_HL : SGM_AGG_PF;                              // prefetch depth (steps): 2 keeps the 8-lines-per-wave kernel at 8 waves/SIMD; the latency-critical 32-lane lines look further ahead
     const int lane = threadIdx.x;
     const int dx = a.dx[dir], dy = a.dy[dir];
     const int W = a.W, H = a.H, Dp = a.Dp;
@@ -407,7 +410,7 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
     const unsigned cbias = (unsigned)(a.dmin + Dp - back);
     const char* const crb = reinterpret_cast<const char*>(fr.census_r - (a.dmin + Dp));
     const char* const clb_base = reinterpret_cast<const char*>(fr.census_l);
-    auto fetch = [&](CensusVec<DPL>& cv, unsigned& cl, int& g) {
+    auto fetch = [&](CensusVec<DPL>& cv, unsigned& cl, uint8_t& g) {
         if constexpr (VOL) {
             load_volume<DPL>(fr.cost + off, cv);
             cl = 0;
@@ -444,7 +447,9 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
         // ---- first pixel of the line: L = C (ref :266-275) ----
         CensusVec<DPL> cv;
         unsigned cl;
-        fetch(cv, cl, g_prev);
+        uint8_t g0;
+        fetch(cv, cl, g0);
+        g_prev = g0;
         const int lim = x - lim_bias;
         if constexpr (VOL) volume_costs<DPL>(cv, Lp);
         else census_costs<DPL>(cl, cv, lim, true, Lp);
@@ -464,9 +469,13 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
     }
 
     // ---- prefetch ring: census-right words, census-left word, grey value, offset, in-image limit ----
+    // The ring's grey values stay BYTES and are widened where a step uses them.  As 32-bit values LLVM zero-extends them at the end
+    // of every pass of the hot loop (one v_and per slot on the just-loaded registers, sunk to the loop latch), so the wave drained
+    // ALL its outstanding loads and plane stores (s_waitcnt vmcnt(0)) every PF steps whatever the prefetch depth.
     CensusVec<DPL> cb[PF];
     unsigned clb[PF];
-    int gb[PF], limb[PF];
+    uint8_t gb[PF];
+    int limb[PF];
     unsigned ob[PF];
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
@@ -486,7 +495,7 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
 
     // one step on ring slot u; `refill` = also fetch step k + PF into the slot
     auto step = [&](int u, bool refill) {
-        const int g = gb[u];
+        const int g = (int)gb[u];
         const int lim = limb[u];
         const unsigned o = ob[u];
         const unsigned dg = __builtin_amdgcn_sad_u8((unsigned)g, (unsigned)g_prev, 0u);   // |g - g_prev| (grey values: one byte)
@@ -515,6 +524,10 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
         g_prev = g;
         if (store_ok) store_cells<DPL>(plane + o, packed);
     };
+    // Everything the prologue has in flight lands before the hot loop (once per line).  The waits inside the loop are placed for
+    // the state merged over BOTH ways into the loop head; with the prologue's loads still pending in whatever order the scheduler
+    // left them, that merge is "wait for everything" -- s_waitcnt vmcnt(0) at the top of EVERY pass, plane stores included.
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0)
     // hot loop: all PF steps and all PF refills are in range, no per-step conditions
     int k0 = 1;
     for (; k0 + 2 * PF - 1 <= nsteps; k0 += PF) {

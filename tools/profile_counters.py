@@ -58,7 +58,10 @@ def main():
     args = ap.parse_args()
     kernels = defaultdict(dict)
     raw = {}
+    big = WORKLOADS[args.workload][0] * WORKLOADS[args.workload][1] * WORKLOADS[args.workload][2] > 100e6
     for tag, ctrs, batch, env in PASSES:
+        if big and batch > 2:
+            batch = 2                  # the large shapes run 2 frames per launch in bench.py (a frame's planes are 4.6 - 11.7 GB)
         d = os.path.join(args.scratch, f"{args.workload}_{tag}")
         os.makedirs(d, exist_ok=True)
         cmd = ["rocprofv3", "--pmc", *ctrs, "--kernel-trace", "-d", d, "-o", tag, "--output-format", "csv", "--",
@@ -99,7 +102,7 @@ def main():
             doc["workloads"] = old.get("workloads", {})
     doc["workloads"][args.workload] = {
         "note": "rocprofv3 --pmc passes of tools/pmc_workload.py; traffic at 1 frame per launch (FETCH_SIZE x2, KiB), SQ counters "
-                "at 8 frames per launch / 8; mean per dispatch without the first (warm-up) one",
+                f"at {2 if big else 8} frames per launch / {2 if big else 8}; mean per dispatch without the first (warm-up) one",
         "kernels": out_k}
     with open(args.out, "w") as f:
         json.dump(doc, f, indent=1)

@@ -4,8 +4,11 @@
 set -x
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-python3 $R/tools/profile_counters.py > $R/gpurun_out/counters.log 2>&1; tail -2 $R/gpurun_out/counters.log
+rm -f $R/gpurun_out/counters.json
+for wl in kitti_1242x375_d128_p8 cone_450x375_d64_p8 drivingstereo_1762x800_d192_p8 middlebury_2880x1988_d256_p8; do
+  python3 $R/tools/profile_counters.py --workload $wl > $R/gpurun_out/counters_$wl.log 2>&1; tail -2 $R/gpurun_out/counters_$wl.log
+done
 cp $R/gpurun_out/counters.json $R/profiles/counters.json          # so that the bench runs below read fresh counters
-rm -rf $R/gpurun_out/prof_stats && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_stats -o stats --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-host-boundary > $R/gpurun_out/bench_under_rocprof.json 2> $R/gpurun_out/prof_stats.log; echo rocprof=$?
-cd $R && sleep 20 && python bench.py --alone > gpurun_out/bench.json 2> gpurun_out/bench.err; echo bench=$?
-python tools/agg_clock.py > gpurun_out/agg_clock.txt 2>/dev/null
+# the driver's own command line under the kernel trace: per-kernel calls / average duration of the timed configuration
+rm -rf $R/gpurun_out/prof_stats && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_stats -o stats --output-format csv -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --legs headline > $R/gpurun_out/bench_under_rocprof.json 2> $R/gpurun_out/prof_stats.log; echo rocprof=$?
+cd $R && sleep 10 && python bench.py --gpus 1 --steps 20 --warmup 5 --alone > gpurun_out/bench.json 2> gpurun_out/bench.err; echo bench=$?

@@ -14,7 +14,8 @@ w, h, d = (1242, 375, 128) if len(sys.argv) < 2 else tuple(int(v) for v in sys.a
 left, right = S.synth_pair(w, h, d, 0x5EED0002)
 opt = S.default_option(d)
 want = None
-for env in ({}, {"SGM_HL": "32"}, {"SGM_HL": "0"}, {"SGM_HL": "64", "SGM_LANES_PER_PIXEL": "8"}, {"SGM_HL": "32", "SGM_LANES_PER_PIXEL": "8"},
+ENVS = ({},) if os.environ.get("SGM_SINGLE_ONLY_DEFAULT") else None
+for env in ENVS or ({}, {"SGM_HL": "32"}, {"SGM_HL": "0"}, {"SGM_HL": "64", "SGM_LANES_PER_PIXEL": "8"}, {"SGM_HL": "32", "SGM_LANES_PER_PIXEL": "8"},
             {"SGM_FUSED_WTA": "1"}):
     for k in ("SGM_HL", "SGM_LANES_PER_PIXEL", "SGM_FUSED_WTA"):
         os.environ.pop(k, None)
