@@ -44,7 +44,27 @@ static int aggregate_any(int ord, void* stream, const sgmd_geom* g, const sgmd_p
     if (debug_mask != 0xFF) a.run_anom = 0;
     if (a.run_anom) blocks += 4;                       // one extra wave per diagonal direction: its anomalous line
     if (blocks == 0) return 0;
-    blocks *= g->B;                                    // every frame of the batch in the same launch
+    // XCD-aware numbering for 2 or 4 frames per launch (sgm_aggregate_k): each of a frame's 8 / B XCDs takes a contiguous strip of
+    // every direction; the grid is 8 x the longest per-XCD list.  Measured (tools/fetch_probe.sh): census reads of the launch
+    // 4.07 -> 1.06 GB per frame at 2880x1988 D=256, 0.34 -> 0.12 GB at 1762x800 D=192.  Not for a single frame: its launch is
+    // bound by the horizontal chains, not by traffic, and runs 7 % longer with the strips (0.340 -> 0.364 ms at KITTI size).
+    // SGM_XCD_STRIPS = 0: never; 2: also for one frame per launch (the counter passes of tools/profile_counters.py run one
+    // frame per launch and use it to see the traffic of the two-frame launches bench.py times).
+    static const int use_strips = getenv("SGM_XCD_STRIPS") ? atoi(getenv("SGM_XCD_STRIPS")) : 1;
+    a.strips = (use_strips && g->B < 8 && 8 % g->B == 0 && (g->B > 1 || use_strips > 1)) ? 8 / g->B : 1;
+    if (a.strips > 1) {
+        int longest = 0;
+        for (int sub = 0; sub < a.strips; ++sub) {
+            int t = 0;
+            for (int d = 0; d <= 8; ++d) {
+                const int n = (d < 8 ? a.block_begin[d + 1] - a.block_begin[d] : (a.run_anom ? 4 : 0));
+                t += (sub + 1) * n / a.strips - sub * n / a.strips;
+            }
+            if (t > longest) longest = t;
+        }
+        blocks = 8 * longest;
+    } else
+        blocks *= g->B;                                // every frame of the batch in the same launch
     const bool pad = (g->D != g->Dp);
     hipStream_t st = (hipStream_t)stream;
     bool launched;

@@ -41,6 +41,7 @@ struct AggArgs {
     int anom_line[8];
     int block_begin[9];
     int ghost_zero;
+    int strips;                 // XCD-aware numbering of the workgroups (see sgm_aggregate_k): XCDs per frame, 1 = plain numbering
 };
 
 // per-frame base pointers of a batched launch (kept apart from the kernel-argument struct so that struct
@@ -698,8 +699,32 @@ __global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
     // Batch: consecutive blocks are the same line group of consecutive frames, so every frame's long
     // horizontal lines are dispatched first.  Per frame, blocks [block_begin[d], block_begin[d+1]) are the
     // regular lines of direction d; the last blocks (one per diagonal direction) are the anomalous lines.
-    const int frame = blockIdx.x % a.B;
-    const int b = blockIdx.x / a.B;
+    //
+    // Workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its own.  With 8 frames per launch frame f's blocks all
+    // land on XCD f and its census images stay in that L2.  With fewer frames (the large shapes run 2 per launch, a single frame 1)
+    // the plain numbering scatters neighbouring line groups -- whose census-right windows overlap almost completely -- over
+    // 8 / B XCDs, and every one of those L2s fetches the same rows (2880x1988 D=256: 5.3 GB of census reads per frame against
+    // 46 MB of census data).  a.strips = 8 / B > 1: the frame keeps its 8 / B XCDs, and each of them takes one CONTIGUOUS strip of
+    // every direction's line groups, in the order horizontal lines first.
+    int frame, b;
+    if (a.strips > 1) {
+        const int xcd = blockIdx.x & 7;
+        frame = xcd % a.B;
+        const int sub = xcd / a.B;
+        int q = blockIdx.x >> 3;
+        b = -1;
+        for (int d = 0; d <= 8; ++d) {                                     // 8 = the anomalous lines
+            const int begin = a.block_begin[d];
+            const int n = (d < 8 ? a.block_begin[d + 1] : begin + (a.run_anom ? 4 : 0)) - begin;
+            const int lo = sub * n / a.strips, share = (sub + 1) * n / a.strips - lo;
+            if (q < share) { b = begin + lo + q; break; }
+            q -= share;
+        }
+        if (b < 0) return;                                                 // the grid is padded to 8 x the longest strip
+    } else {
+        frame = blockIdx.x % a.B;
+        b = blockIdx.x / a.B;
+    }
     AggFrame fr;
     fr.img = a.img + (size_t)frame * a.W * a.H;
     fr.census_l = a.census_l + (size_t)frame * a.W * a.H;

@@ -62,6 +62,8 @@ def main():
     for tag, ctrs, batch, env in PASSES:
         if big and batch > 2:
             batch = 2                  # the large shapes run 2 frames per launch in bench.py (a frame's planes are 4.6 - 11.7 GB)
+        if big and batch == 1:
+            env = dict(env, SGM_XCD_STRIPS="2")     # ... with the XCD-aware block numbering, which one frame per launch does not use by itself
         d = os.path.join(args.scratch, f"{args.workload}_{tag}")
         os.makedirs(d, exist_ok=True)
         cmd = ["rocprofv3", "--pmc", *ctrs, "--kernel-trace", "-d", d, "-o", tag, "--output-format", "csv", "--",
