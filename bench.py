@@ -5,14 +5,15 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W [--mode tiles]
 
---mode frames (default).  A "step" is one pass of the hot path over ONE BATCH of --batch frames through the HOST-pointer
-boundary -- SURVEY.md 8(d)'s t_frame: sgm_reset + sgm_match_async + sgm_match_wait (the reference's SGM_Reset + SGM_Match,
+--mode frames (default).  A "step" is one pass of the hot path over ONE BATCH of --host-instances x --batch frames (defaults 4 x 8 =
+32: BASELINE config 4's "batch of 32 KITTI frames") through the HOST-pointer boundary -- SURVEY.md 8(d)'s t_frame: every instance
+takes a sub-batch of --batch frames through sgm_reset + sgm_match_async + sgm_match_wait (the reference's SGM_Reset + SGM_Match,
 SemiGlobalMatching.c:77-78,122: borrowed host images in, host floats out) on page-locked caller buffers, i.e. H2D of the
-images, every kernel, D2H of the disparity maps.  --host-instances instances take the steps round-robin, each driven by its own
-host thread, so the copies of one batch overlap the kernels of the others.  Every kernel of the pipeline covers all frames of
-the batch in one launch.  All stages run (census, cost, 8-path aggregation, WTA, LR check, speckle removal, median = the
-options of the reference's main.c).  Frames are independent units, so with N GPUs every rank processes its own K batches --
-its share (sharding.frames_of_rank) of a 32-frame KITTI pool -- (weak scaling, no data-path collective); `value` is the
+images, every kernel, D2H of the disparity maps; each instance is driven by its own host thread, so the copies of one sub-batch
+overlap the kernels of the others, and every kernel of the pipeline covers the --batch frames of its sub-batch in one launch.
+All stages run (census, cost, 8-path aggregation, WTA, LR check, speckle removal, median = the options of the reference's
+main.c).  Frames are independent units, so with N GPUs every rank processes its own K batches -- its share
+(sharding.frames_of_rank) of the 32-frame KITTI pool, cycled -- (weak scaling, no data-path collective); `value` is the
 whole-job aggregate.  Beside it in the same JSON line (N = 1): `device_resident` (the same frames already in HBM: kernels
 only), `sustained` (the headline loop for >= 2 s), `host_boundary` (the blocking one-frame-per-call contract, pageable
 buffers), `workloads` (the other single-GPU BASELINE configs: cone 8 / 4 paths, 2880x1988 D=256, 1762x800 D=192, each with
@@ -280,9 +281,10 @@ def merge_timing(insts):
 
 
 class HostPipeline:
-    """The host-pointer boundary as a caller with a stream of frames uses it: n instances, each driven by its own host thread,
-    take the steps round-robin; a step = sgm_reset + sgm_match_async + sgm_match_wait on one batch of B frames in page-locked
-    caller buffers (H2D, every kernel, D2H).  Each instance writes its results into a small ring of output buffers, so the last
+    """The host-pointer boundary as a caller with a stream of frames uses it: n instances, each driven by its own host thread.  A step is
+    one pass over a batch of n x B frames (at the defaults 4 x 8 = BASELINE config 4's batch of 32 KITTI frames): every instance
+    takes a sub-batch of B frames through sgm_reset + sgm_match_async + sgm_match_wait on page-locked caller buffers (H2D, every
+    kernel -- one launch per stage covers the B frames --, D2H).  Each instance writes its results into a small ring of output buffers, so the last
     `keep` batches of every instance can be verified after the timed region."""
 
     def __init__(self, S, device, w, h, opt, B, batches, n_inst, keep=4, cu_split="", overlap_post=True, honor4=False, timing=True):
@@ -313,11 +315,12 @@ class HostPipeline:
             for i in self.insts:
                 i.enable_timing(True)
 
-    def _worker(self, k, steps, barrier, fail):
+    def _worker(self, k, first_step, n_steps, barrier, fail):
         inst = self.insts[k]
+        n = len(self.insts)
         barrier.wait()
-        for s in steps:
-            b = s % len(self.inputs)
+        for s in range(first_step, first_step + n_steps):
+            b = (s * n + k) % len(self.inputs)                   # step s = sub-batches s*n .. s*n + n-1 of the pool, one per instance
             slot = self.done[k] % self.keep
             L, R = self.inputs[b]
             if not (inst.reset(self.w, self.h, self.opt) and inst.match_async(L, R, self.outs[k][slot]) and inst.match_wait()):
@@ -327,13 +330,13 @@ class HostPipeline:
             self.done[k] += 1
 
     def run(self, first_step, n_steps, before=None):
-        """Steps first_step .. first_step + n_steps - 1, step s on instance s mod n; returns the wall time from the moment every
-        thread is ready to the moment the last result has been handed over."""
+        """Steps first_step .. first_step + n_steps - 1.  A step is one pass over n x B frames: every instance takes one sub-batch of B
+        frames (one launch per stage covers them).  Returns the wall time from the moment every thread is ready to the moment the
+        last result has been handed over."""
         n = len(self.insts)
         fail = []
         barrier = threading.Barrier(n + 1)
-        th = [threading.Thread(target=self._worker, args=(k, [s for s in range(first_step, first_step + n_steps) if s % n == k], barrier, fail))
-              for k in range(n)]
+        th = [threading.Thread(target=self._worker, args=(k, first_step, n_steps, barrier, fail)) for k in range(n)]
         for t in th:
             t.start()
         if before:
@@ -348,7 +351,7 @@ class HostPipeline:
         return el
 
     def run_for(self, seconds, first_step=0):
-        """The same loop until `seconds` have passed; returns (elapsed, steps)."""
+        """The same loop until `seconds` have passed; returns (elapsed, sub-batches of B frames processed)."""
         n = len(self.insts)
         fail, counts = [], [0] * n
         barrier = threading.Barrier(n + 1)
@@ -357,9 +360,9 @@ class HostPipeline:
         def worker(k):
             inst = self.insts[k]
             barrier.wait()
-            s = first_step + k
+            s = first_step
             while time.perf_counter() < stop[0]:
-                b = s % len(self.inputs)
+                b = (s * n + k) % len(self.inputs)
                 slot = self.done[k] % self.keep
                 L, R = self.inputs[b]
                 if not (inst.reset(self.w, self.h, self.opt) and inst.match_async(L, R, self.outs[k][slot]) and inst.match_wait()):
@@ -368,7 +371,7 @@ class HostPipeline:
                 self.held[k][slot] = b
                 self.done[k] += 1
                 counts[k] += 1
-                s += n
+                s += 1
         th = [threading.Thread(target=worker, args=(k,)) for k in range(n)]
         for t in th:
             t.start()
@@ -537,11 +540,12 @@ def blocking_leg(S, w, h, d, opt, pairs, seeds, digests, budget_s=2.0):
     """The reference contract as it stands: sgm_compute (SGM_Reset + SGM_Match) per frame on pageable arrays, one frame at a time."""
     g = S.SGM()
     n, t_sum, out = 0, 0.0, None
+    buf = np.zeros((h, w), np.float32)                   # the caller's output buffer, allocated once as in the reference's main.c:86
     t_begin = time.perf_counter()
     while n < 400 and time.perf_counter() - t_begin < budget_s:
         l, r = pairs[n % len(pairs)]
         t0 = time.perf_counter()
-        out = g.compute(l, r, opt)
+        out = g.compute(l, r, opt, out=buf)
         dt = time.perf_counter() - t0
         if out is None:
             g.shutdown()
@@ -647,7 +651,7 @@ def run_frames(args):
     #      of B; a rank with fewer than 2 B frames cycles through its share
     pool = POOL_FRAMES if len(digests) >= POOL_FRAMES else max(2 * B, 1)
     mine = frames_of_rank(pool, world, rank) or [rank % max(pool, 1)]
-    n_batches = max(2, len(mine) // B)
+    n_batches = max(n_host, 2, len(mine) // B)
     batch_frames = [[mine[(k * B + j) % len(mine)] for j in range(B)] for k in range(n_batches)]
     batch_seeds = [[seed + f for f in fr] for fr in batch_frames]
     pair_of = {f: S.synth_pair(w, h, d, seed + f) for f in sorted({f for fr in batch_frames for f in fr})}
@@ -680,7 +684,7 @@ def run_frames(args):
     if "sustained" in legs:
         el2, steps2 = hp.run_for(max(2.0, args.sustain_seconds), first_step=args.warmup + args.steps)
         ok2, bad2, unp2 = hp.verify(batch_seeds, digests)
-        sustained = {"seconds": round(el2, 3), "steps": steps2, "frames": steps2 * B, "fps": round(steps2 * B / el2, 2),
+        sustained = {"seconds": round(el2, 3), "sub_batches": steps2, "frames": steps2 * B, "fps": round(steps2 * B / el2, 2),
                      "value": round(w * h * d * npaths * steps2 * B / el2 / 1e6, 1), "unit": "Mdisp/s",
                      "frames_verified": ok2, "frames_mismatched": bad2,
                      "note": "the headline loop run for a fixed time instead of a fixed number of steps"}
@@ -704,7 +708,7 @@ def run_frames(args):
             dev["fps_all_ranks"] = round(float(t[0].item()), 2)
 
     if rank == 0:
-        total_frames = args.steps * B * world
+        total_frames = args.steps * B * n_host * world
         cells = w * h * d
         value = cells * npaths * total_frames / elapsed / 1e6
         line = {
@@ -719,11 +723,13 @@ def run_frames(args):
                        "stages": "census+cost+aggregate8+wta+lrcheck+speckle+median" if npaths == 8 else "census+cost+aggregate4+wta+lrcheck+speckle+median",
                        "entry": "sgm_reset + sgm_match_async + sgm_match_wait on page-locked host buffers: H2D + kernels + D2H per step "
                                 "(the reference's SGM_Reset + SGM_Match contract, SemiGlobalMatching.c:77-78,122)",
-                       "frames_per_step": B, "frames_per_gpu": args.steps * B, "instances_per_gpu": n_host, "host_threads_per_gpu": n_host,
+                       "frames_per_step": B * n_host, "frames_per_launch": B, "frames_per_gpu": args.steps * B * n_host,
+                       "step": f"one pass over a batch of {B * n_host} frames: {n_host} instances x one sub-batch of {B} frames each (every kernel covers its {B} frames in one launch)",
+                       "instances_per_gpu": n_host, "host_threads_per_gpu": n_host,
                        "post_pass_on_second_stream": bool(overlap_post) or "post" in cu_split, "stage_cus_per_xcd": cu_split or None,
                        "frame_pool": pool, "frames_of_rank0": mine,
                        "sharding": "independent frames per rank (sharding.frames_of_rank over the pool), no collective"},
-            "ms_per_frame": round(elapsed / (args.steps * B) * 1e3, 4),
+            "ms_per_frame": round(elapsed / (args.steps * B * n_host) * 1e3, 4),
             "stage_ms_per_batch_launch": {k: round(v, 4) for k, v in stage_ms.items()},
             "frames_verified": n_ok, "frames_mismatched": n_bad, "frames_without_reference_digest": n_unp,
             "verified_against_golden": (n_bad == 0 and n_ok > 0 and n_unp == 0),
@@ -830,8 +836,8 @@ def run_frames(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400, help="timed steps (a step = one batch through the host-pointer boundary)")
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=150, help="timed steps (a step = one batch of host-instances x batch frames through the host-pointer boundary)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--mode", default="frames", choices=["frames", "tiles"])
     ap.add_argument("--batch", type=int, default=None,
                     help="frames per step, one launch per stage covers them all (frames mode: default 8; tiles mode: default 1 = "

@@ -272,11 +272,15 @@ class SGM(_StageReader):
         ok = self.lib.SGM_Match(left.ctypes.data, right.ctypes.data, out.ctypes.data)
         return out if ok else None
 
-    def compute(self, left, right, option):
-        """sgm_compute: SGM_Reset + SGM_Match in one call (north_star's entry point).  None where it returns false."""
+    def compute(self, left, right, option, out=None):
+        """sgm_compute: SGM_Reset + SGM_Match in one call (north_star's entry point).  None where it returns false.  `out`: a
+        C-contiguous float32 [H][W] array to write into (a caller with a stream of frames allocates it once)."""
         left, right = _u8(left), _u8(right)
         h, w = left.shape
-        out = np.empty((h, w), np.float32)
+        if out is None:
+            out = np.empty((h, w), np.float32)
+        elif out.dtype != np.float32 or tuple(out.shape) != (h, w) or not out.flags["C_CONTIGUOUS"]:
+            raise ValueError(f"compute: out must be a C-contiguous float32 array of shape {(h, w)}")
         ok = self.lib.sgm_compute(left.ctypes.data, right.ctypes.data, w, h, C.byref(option), out.ctypes.data)
         if ok:
             self.shape = (h, w, option.max_disparity - option.min_disparity)

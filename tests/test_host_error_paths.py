@@ -188,6 +188,34 @@ def test_async_match_hands_over_at_wait(host):
     L.sgm_destroy(s)
 
 
+def test_staged_result_is_handed_over_in_pieces(host):
+    """A result of 256 KiB or more that has to be staged (pageable caller buffer) comes back in four pieces with an event behind
+    each of the first three; sgm_match_wait copies piece i to the caller while piece i + 1 is still on the bus, and the caller
+    ends up with exactly the staged bytes."""
+    L = host
+    L.sgm_match_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.sgm_match_wait.argtypes = [C.c_void_p]
+    s, opt = fresh(L)
+    w, h = 320, 240                                                  # 300 KiB of disparities
+    assert L.sgm_reset(s, w, h, C.byref(opt))
+    img = np.zeros((h, w), np.uint8)
+    out = np.full((h, w), -1.0, np.float32)
+    L.stub_clear()
+    assert L.sgm_match_async(s, img.ctypes.data, img.ctypes.data, out.ctypes.data)
+    names = [L.stub_log_name(i).decode() for i in range(L.stub_log_size())]
+    tail = names[names.index("median") + 1:]
+    assert tail == ["d2h", "event_record", "d2h", "event_record", "d2h", "event_record", "d2h"]
+    sizes = [L.stub_log_arg(i) for i in range(L.stub_log_size()) if L.stub_log_name(i) == b"d2h"]
+    assert sum(sizes) == w * h * 4 and all(n % 4 == 0 for n in sizes)
+    assert names.index("h2d") < names.index("census")
+    L.stub_clear()
+    assert L.sgm_match_wait(s)
+    names = [L.stub_log_name(i).decode() for i in range(L.stub_log_size())]
+    assert names.count("event_sync") == 3 and names[-1] == "sync"
+    assert not np.any(out == -1.0)                                   # every piece reached the caller (the stub's device memory is zeroed)
+    L.sgm_destroy(s)
+
+
 def test_row_tile_instance_allocates_a_tile_not_a_frame(host):
     """Row-tile mode: the per-direction planes have storage for the tile's rows + one hand-over row either side, the
     frame-sized S and cost volumes are not allocated at all (nothing on the tile path reads or writes them)."""
