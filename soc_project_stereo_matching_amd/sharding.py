@@ -3,8 +3,8 @@
 Frames are independent units of the hot path, so the data path needs no collective:
 rank r owns every frame whose index is congruent to r modulo the world size, matches them on its own
 GPU, and -- only if the caller wants the results in one place -- the disparity maps are gathered to
-rank 0 with torch.distributed.  `matcher` is any callable (left, right) -> float32 disparity: in the
-product it is an `SGMStream` over libsgm_mi355x.so; the CPU tests plug in the oracle to exercise
+rank 0 with one torch.distributed tensor gather (device tensors over RCCL, host tensors over gloo).
+`matcher` is any callable (left, right) -> float32 disparity: in the product it is an `SGMStream` over libsgm_mi355x.so; the CPU tests plug in the oracle to exercise
 this host logic with the gloo backend.
 """
 from __future__ import annotations
@@ -80,14 +80,22 @@ def match_sharded(frames: Sequence[Tuple[np.ndarray, np.ndarray]], matcher: Call
         return [local[i] for i in mine]
     if world == 1:
         return [local[i] for i in range(len(frames))]
-    gathered = [None] * world if rank == 0 else None
-    dist.gather_object(local, gathered, dst=0)
+    # one tensor gather of the ranks' maps (padded to the largest share): device buffers over RCCL when the matcher returns device
+    # tensors, host tensors over gloo in the CPU tests -- nothing is pickled through the host
+    import torch
+    most = -(-len(frames) // world)
+    first = next(iter(local.values())) if local else None
+    shape = [most] + list(first.shape if first is not None else np.shape(frames[0][0]))
+    on_device = (torch.is_tensor(first) and first.is_cuda) or (first is None and dist.get_backend() == "nccl")   # a rank without frames follows the backend
+    mine_t = torch.zeros(shape, dtype=torch.float32, device=(first.device if first is not None else "cuda") if on_device else "cpu")
+    for k, i in enumerate(mine):
+        mine_t[k] = local[i] if torch.is_tensor(local[i]) else torch.from_numpy(np.ascontiguousarray(local[i], dtype=np.float32))
+    parts = [torch.empty_like(mine_t) for _ in range(world)] if rank == 0 else None
+    dist.gather(mine_t, parts, dst=0)
     if rank != 0:
         return None
-    merged = {}
-    for part in gathered:
-        merged.update(part)
-    missing = [i for i in range(len(frames)) if i not in merged]
-    if missing:
-        raise RuntimeError(f"frames {missing} were not matched by any rank")
-    return [merged[i] for i in range(len(frames))]
+    out = []
+    for i in range(len(frames)):
+        m = parts[i % world][i // world]                     # frame i is the (i // world)-th frame of rank i % world
+        out.append(m if on_device else m.numpy())
+    return out

@@ -1,4 +1,4 @@
-"""The C-ABI library loads without a GPU and exports every symbol include/sgm_mi355x.h declares.
+"""The C-ABI library loads without a GPU and exports every symbol include/sgm_mi355x.h and include/sgm_tiles.h declare.
 No compute call is made here."""
 import ctypes as C
 import os
@@ -9,14 +9,17 @@ import pytest
 
 from conftest import ROOT
 
-HEADER = os.path.join(ROOT, "include", "sgm_mi355x.h")
+HEADERS = [os.path.join(ROOT, "include", h) for h in ("sgm_mi355x.h", "sgm_tiles.h")]
 
 
 def _declared_functions():
-    text = open(HEADER).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"\b((?:SGM_|sgm_)\w+)\s*\(", text)
-    return sorted(set(names))
+    names = set()
+    for header in HEADERS:
+        text = open(header).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"typedef[^;{]*\(\s*\*\s*\w+\s*\)[^;]*;", "", text)          # function-pointer typedefs are not symbols
+        names.update(re.findall(r"\b((?:SGM_|sgm_)\w+)\s*\(", text))
+    return sorted(names)
 
 
 @pytest.fixture(scope="module")
@@ -36,6 +39,9 @@ def test_every_declared_symbol_is_exported(lib):
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     assert len(names) >= 25
+    for must in ("sgm_tile_step", "sgm_tiles_create", "sgm_tiles_submit", "sgm_tiles_finish", "sgm_tiles_rccl_transport",
+                 "sgm_tiles_local_transport"):
+        assert must in names
 
 
 def test_option_struct_abi():
