@@ -1,17 +1,15 @@
 #!/usr/bin/env bash
-# Runs bench.py (KITTI batches, no CPU baseline / host boundary) once per library build under variants/ and
-# once on the in-tree build, with one and two batches in flight; prints fps and the two heavy kernels' launch times.
+# Runs bench.py (KITTI batches; device-resident leg alone and in flight, sustained host pipeline) once per library build under
+# variants/ (tools/build_variant.sh) and once on the in-tree build.  On the GPU box.
 cd "$(dirname "${BASH_SOURCE[0]}")/.."
 for lib in intree variants/*/libsgm_mi355x.so; do
-  for fl in 1 2; do
     if [ "$lib" = intree ]; then unset SGM_LIBRARY_PATH; name=intree; else export SGM_LIBRARY_PATH="$PWD/$lib"; name=$(basename "$(dirname "$lib")"); fi
-    out=gpurun_out/sweep_${name}_f${fl}.json
-    timeout -k 10 200 python bench.py --steps 40 --warmup 8 --in-flight $fl --no-cpu-baseline --no-host-boundary > "$out" 2>> gpurun_out/sweep.err || { echo "$name f$fl FAILED"; exit 1; }
-    python - "$out" "$name" "$fl" <<'PY'
+    out=gpurun_out/sweep_${name}.json
+    timeout -k 10 300 python bench.py --steps 40 --warmup 8 --legs device,sustained --alone "$@" > "$out" 2>> gpurun_out/sweep.err || { echo "$name FAILED"; continue; }
+    python - "$out" "$name" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
-s = d["stage_ms_per_batch_launch"]
-print(f"{sys.argv[2]:28s} in-flight {sys.argv[3]}: {d['fps']:8.1f} fps  aggregate {s['aggregate']:.4f}  sum {s['sum']:.4f}  median {s['median']:.4f}  verified {d['frames_verified']}/{d['frames_verified'] + d['frames_mismatched']}", flush=True)
+dv = d["device_resident"]; s = dv["stage_ms_per_batch_launch"]; al = dv["roofline"].get("alone", {}); als = dv["roofline_sum_wta"].get("alone", {})
+print(f"{sys.argv[2]:16s} host {d['sustained']['fps']:7.1f} fps  device {dv['fps']:7.1f} fps  agg {s['aggregate']:.3f} (alone {al.get('avg_launch_ms')})  sum {s['sum']:.3f} (alone {als.get('avg_launch_ms')})  verified {dv['frames_verified']}/{dv['frames_verified'] + dv['frames_mismatched']}", flush=True)
 PY
-  done
 done
