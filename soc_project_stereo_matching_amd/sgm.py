@@ -9,11 +9,13 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_LOAD_LOCK = threading.Lock()
 
 STAGE_NAMES = ["census_l", "census_r", "cost", "aggr", "disp_l", "disp_r", "after_lr", "after_speckle", "final"]
 _STAGE_DTYPE = [np.uint32, np.uint32, np.uint8, np.uint16] + [np.float32] * 5
@@ -68,6 +70,13 @@ def load_library() -> C.CDLL:
     global _LIB
     if _LIB is not None:
         return _LIB
+    with _LOAD_LOCK:                                  # callers may be threads (ranks of a tile pipeline, host threads of a stream)
+        if _LIB is None:
+            _LIB = _load()
+    return _LIB
+
+
+def _load() -> C.CDLL:
     path = library_path()
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: build it with `make -C soc_project_stereo_matching_amd/csrc` "
@@ -165,7 +174,6 @@ def load_library() -> C.CDLL:
     L.sgm_host_anomalous_line.argtypes = [C.c_int, C.c_int]
     L.sgm_host_anomalous_line.restype = C.c_int
     L.sgm_host_p2_table.argtypes = [C.c_int, C.c_int, C.c_void_p]
-    _LIB = L
     return L
 
 

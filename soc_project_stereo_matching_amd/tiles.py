@@ -15,6 +15,7 @@ The reference has no multi-GPU code; the call site this se
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 from .sgm import load_library
 
@@ -60,14 +61,25 @@ class Transport(C.Structure):
 
 _RESULT_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p)
 _BOUND = False
+_BIND_LOCK = threading.Lock()
 
 
 def lib():
     """The library with the sgm_tiles.h prototypes attached."""
-    global _BOUND
     L = load_library()
     if _BOUND:
         return L
+    # ranks may be threads of one process: the first use must not race.  (ctypes creates a function object per first attribute
+    # access; two threads binding at once can leave the cached object without prototypes, and a `long` or a pointer then goes
+    # through as a 32-bit int.)
+    with _BIND_LOCK:
+        if not _BOUND:
+            _bind(L)
+    return L
+
+
+def _bind(L):
+    global _BOUND
     i, p = C.c_int, C.c_void_p
     L.sgm_tile_rows.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
     L.sgm_tile_rows.restype = C.c_bool

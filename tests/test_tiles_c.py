@@ -383,3 +383,33 @@ def test_results_reach_their_owner_in_order_and_a_refused_launch_fails_the_submi
     assert not L.sgm_tiles_create(0, 0, 20, w, h, C.byref(opt), 1, 2, 1, 0, None)
     assert not L.sgm_tiles_create(0, 0, 2, w, h, C.byref(opt), 1, 2, 1, 0, None)
     assert not L.sgm_tiles_create(0, 3, 2, w, h, C.byref(opt), 1, 2, 1, 0, None)
+
+
+def test_first_use_from_several_threads_at_once():
+    """Ranks may be threads of one process and reach the library for the first time together (tools/fuzz_parity.py did): the
+    prototypes must be attached exactly once -- a racing first use once left a function object without them, and `long`
+    arguments went through as 32-bit ints.  A fresh interpreter, eight threads, frame numbers beyond 2^32."""
+    import sys
+    code = r'''
+import sys, threading
+sys.path.insert(0, %r)
+from soc_project_stereo_matching_amd import tiles
+bad, go = [], threading.Barrier(8)
+def worker(k):
+    go.wait()
+    seen = []
+    eng = tiles.PyEngine(lambda s, f: seen.append(f), *([lambda *a: None] * 6))
+    big = (1 << 33) + k
+    if tiles.steps_total(big, 1, 0) != big + 3:
+        bad.append(("steps_total", k))
+    eng.step(0, 1, 8, 2, 0, big, big + 1)
+    if seen != [big]:
+        bad.append(("begin", k, seen))
+th = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+[t.start() for t in th]; [t.join() for t in th]
+print("bad:", bad)
+sys.exit(1 if bad else 0)
+''' % ROOT
+    for _ in range(3):
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, (out.stdout[-500:], out.stderr[-1500:])

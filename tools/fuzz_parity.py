@@ -66,7 +66,8 @@ def pipe_case(orc, rng, w, h, d, opt, seed, kw):
 
             TilePipeline(eng, r, ranks, h, dist=group.view(r), lead=lead).run(steps, lambda f: dev[f], on_result)
         except Exception as exc:                                    # noqa: BLE001
-            errors.append((r, repr(exc)))
+            import traceback
+            errors.append((r, repr(exc), traceback.format_exc()[-600:]))
         finally:
             if eng is not None:
                 eng.close()
@@ -85,6 +86,56 @@ def pipe_case(orc, rng, w, h, d, opt, seed, kw):
             bad = not same(g, orc.run(frames[k][j][0], frames[k][j][1], opt)["final"])
     if bad:
         print(f"MISMATCH pipeline {w}x{h} d={d} ranks={ranks} B={B} steps={steps} lead={lead} seed={seed} errors={errors} opts={kw}", flush=True)
+    return int(bad)
+
+
+def cpipe_case(orc, rng, w, h, d, opt, seed, kw):
+    """the C host of the tile pipeline (include/sgm_tiles.h): 1..5 ranks as threads over its local transport, batches of 1..3 frames
+    per step, a lead of 0..3, more frames than slots now and then; every frame against the oracle"""
+    import threading
+    import torch
+    from soc_project_stereo_matching_amd import tiles
+    ranks = int(min(h, rng.integers(1, 6)))
+    B, steps, lead = int(rng.integers(1, 4)), int(rng.integers(1, 12)), int(rng.integers(0, 4))
+    frames = [[orc.synth_pair(w, h, d, seed + 8 * k + j) for j in range(B)] for k in range(steps)]
+    dev = [(torch.from_numpy(np.stack([p[0] for p in fr])).cuda(), torch.from_numpy(np.stack([p[1] for p in fr])).cuda()) for fr in frames]
+    torch.cuda.synchronize()
+    ring_frames = (steps + ranks - 1) // ranks
+    rings = [torch.full((ring_frames, B, h, w), -3.0, dtype=torch.float32, device="cuda") for _ in range(ranks)]
+    group = tiles.LocalGroup(ranks, 0) if ranks > 1 else None
+    errors = []
+    throttle = int(rng.integers(0, 4))                              # (the generator is not for the threads to share)
+
+    def rank_main(r):
+        try:
+            tr = group.transport(r) if group else None
+            pipe = tiles.TilesPipeline(0, r, ranks, w, h, opt, batch=B, lead=lead, throttle=throttle, transport=tr)
+            pipe.result_ring(rings[r].data_ptr(), ring_frames)
+            for k in range(steps):
+                assert pipe.submit(dev[k][0].data_ptr(), dev[k][1].data_ptr()), f"submit {k}"
+            assert pipe.finish(), "finish"
+            pipe.close()
+            if tr is not None:
+                tr.close()
+        except BaseException as exc:                                # noqa: BLE001
+            errors.append((r, repr(exc)))
+
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(ranks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(180)
+    if group:
+        group.close()
+    bad = bool(errors)
+    for k in range(steps):
+        got = rings[k % ranks][(k // ranks) % ring_frames].cpu().numpy()
+        for j in range(B):
+            if bad:
+                break
+            bad = not same(got[j], orc.run(frames[k][j][0], frames[k][j][1], opt)["final"])
+    if bad:
+        print(f"MISMATCH cpipe {w}x{h} d={d} ranks={ranks} B={B} steps={steps} lead={lead} seed={seed} errors={errors} opts={kw}", flush=True)
     return int(bad)
 
 
@@ -140,7 +191,7 @@ def main():
                   uniqueness_ratio=float(rng.choice([0.99, 0.95, 0.8])), lrcheck_thres=float(rng.choice([1.0, 0.0, 2.5])))
         opt = default_option(dmin + d, dmin, **kw)
         seed = int(rng.integers(1, 2**31))
-        modes = os.environ.get("FUZZ_MODES", "plain,plain,batch,separate,window,rightview,tiles,planes,pipe").split(",")
+        modes = os.environ.get("FUZZ_MODES", "plain,plain,batch,batch,separate,window,rightview,tiles,planes,pipe,cpipe").split(",")
         mode = str(rng.choice(modes))
         if mode == "tiles" and h < 4:
             mode = "plain"
@@ -153,6 +204,10 @@ def main():
             win = [(7, 7), (9, 7), (3, 5), (7, 9), (1, 1), (63, 1)][int(rng.integers(0, 6))]
         orc.set_census_window(*win)
         orc.set_reference_view(mode == "rightview")
+        if mode == "cpipe" and h >= 5:
+            n += 1
+            bad += cpipe_case(orc, rng, w, h, d, opt, seed, kw)
+            continue
         if mode == "pipe" and h >= 4:
             n += 1
             bad += pipe_case(orc, rng, w, h, d, opt, seed, kw)
