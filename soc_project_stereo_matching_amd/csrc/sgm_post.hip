@@ -231,7 +231,9 @@ __global__ __launch_bounds__(256) void sgm_speckle_apply_k(float* __restrict__ d
 
 #define MED_PF 4                 // batches (4 steps each) of pre-sorted inputs kept in flight per wave
 #define MED_NE 6                 // float4 planes per time slot: 5 pre-sorted originals + the row above a band
+#ifndef MED_SKEW
 #define MED_SKEW 3
+#endif
 #define MED_LAG (MED_SKEW * 63)
 #define MED_RING 128
 #define MED_WAVES 8                // waves (64 rows each) per workgroup: 512 threads leave 256 VGPRs per lane
@@ -336,7 +338,10 @@ __global__ __launch_bounds__(64 * MED_WAVES) void sgm_median_serial_k(const floa
             const float* const top_row = disp + (size_t)(yr - 1) * W;
             const float4* Pg = P + (size_t)g * Tq * MED_NE * 64 + l;
 
-            float o1 = 0.f, o2 = 0.f;                                // own outputs of the last two steps
+            float o1 = 0.f;                                          // own output of the last step (in-row chain)
+            float oh[MED_SKEW - 1];                                  // own outputs of the last MED_SKEW - 1 steps, oh[0] = o1
+#pragma unroll
+            for (int k = 0; k < MED_SKEW - 1; ++k) oh[k] = 0.f;
             float T0 = 0.f;                                          // out(y-1, x-1)
             float T1 = top_row[0];                                   // out(y-1, x): column 0 is border, never modified
             asm volatile("" : "+v"(T1));                             // retire this load here, not at its first use inside the loop
@@ -369,8 +374,8 @@ __global__ __launch_bounds__(64 * MED_WAVES) void sgm_median_serial_k(const floa
                     const int x = t0 + j - MED_SKEW * l;
                     const float e0 = (&ev[0].x)[j], e1 = (&ev[1].x)[j], e2 = (&ev[2].x)[j], e3 = (&ev[3].x)[j],
                                 e4 = (&ev[4].x)[j];
-                    // out(y-1, x+1): produced by the lane above two steps ago (its o2); lane 0 takes the top row
-                    const float b = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(tv[j]), __float_as_int(o2),
+                    // out(y-1, x+1): produced by the lane above MED_SKEW - 1 steps ago; lane 0 takes the top row
+                    const float b = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(tv[j]), __float_as_int(oh[MED_SKEW - 2]),
                                                                                0x138 /* wave_shr:1 */, 0xF, 0xF, false));
                     const float lo = fminf(fminf(T0, T1), b), hi = fmaxf(fmaxf(T0, T1), b);
                     const float mid = __builtin_amdgcn_fmed3f(T0, T1, b);
@@ -379,7 +384,9 @@ __global__ __launch_bounds__(64 * MED_WAVES) void sgm_median_serial_k(const floa
                     const float outv = __builtin_amdgcn_fmed3f(s3, o1, s4);   // border columns: s3 == s4 == original
                     res[j] = outv;
                     T0 = T1; T1 = b;
-                    o2 = o1; o1 = outv;
+#pragma unroll
+                    for (int k = MED_SKEW - 2; k > 0; --k) oh[k] = oh[k - 1];
+                    oh[0] = o1 = outv;
                     ring_dst[(unsigned)(x - 1) & ring_mask] = outv;
                 }
                 // results go to the time-skewed, lane-interleaved buffer O (one coalesced 1 KiB store per batch;
@@ -493,7 +500,10 @@ __global__ __launch_bounds__(64 * WAVES) void sgm_median_chain_k(const float* __
             const float* const top_row = disp + (size_t)(yr - 1) * W;
             const float4* Pg = P + (size_t)g * Tq * MED_NE * 64 + l;
 
-            float o1 = 0.f, o2 = 0.f;                                // own outputs of the last two steps
+            float o1 = 0.f;                                          // own output of the last step (in-row chain)
+            float oh[MED_SKEW - 1];                                  // own outputs of the last MED_SKEW - 1 steps, oh[0] = o1
+#pragma unroll
+            for (int k = 0; k < MED_SKEW - 1; ++k) oh[k] = 0.f;
             float T0 = 0.f;                                          // out(y-1, x-1)
             float T1 = top_row[0];                                   // out(y-1, x): column 0 is border, never modified
             asm volatile("" : "+v"(T1));                             // retire this load here, not at its first use inside the loop
@@ -526,8 +536,8 @@ __global__ __launch_bounds__(64 * WAVES) void sgm_median_chain_k(const float* __
                     const int x = t0 + j - MED_SKEW * l;
                     const float e0 = (&ev[0].x)[j], e1 = (&ev[1].x)[j], e2 = (&ev[2].x)[j], e3 = (&ev[3].x)[j],
                                 e4 = (&ev[4].x)[j];
-                    // out(y-1, x+1): produced by the lane above two steps ago (its o2); lane 0 takes the top row
-                    const float b = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(tv[j]), __float_as_int(o2),
+                    // out(y-1, x+1): produced by the lane above MED_SKEW - 1 steps ago; lane 0 takes the top row
+                    const float b = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(tv[j]), __float_as_int(oh[MED_SKEW - 2]),
                                                                                0x138 /* wave_shr:1 */, 0xF, 0xF, false));
                     const float lo = fminf(fminf(T0, T1), b), hi = fmaxf(fmaxf(T0, T1), b);
                     const float mid = __builtin_amdgcn_fmed3f(T0, T1, b);
@@ -536,7 +546,9 @@ __global__ __launch_bounds__(64 * WAVES) void sgm_median_chain_k(const float* __
                     const float outv = __builtin_amdgcn_fmed3f(s3, o1, s4);   // border columns: s3 == s4 == original
                     res[j] = outv;
                     T0 = T1; T1 = b;
-                    o2 = o1; o1 = outv;
+#pragma unroll
+                    for (int k = MED_SKEW - 2; k > 0; --k) oh[k] = oh[k - 1];
+                    oh[0] = o1 = outv;
                     ring_dst[(unsigned)(x - 1) & ring_mask] = outv;
                 }
                 // results go to the time-skewed, lane-interleaved buffer O (one coalesced 1 KiB store per batch;
