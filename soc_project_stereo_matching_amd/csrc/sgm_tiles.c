@@ -502,8 +502,14 @@ static int local_send(void* c, const void* buf, size_t bytes, int peer, void* st
         m->cap = bytes;
     }
     /* the previous receiver must have copied the stage out before it is overwritten */
-    if (m->used_before && sgmd_stream_wait_event(g->device, stream, m->ev_taken) != 0) return -1;
-    if (sgmd_d2d_async(g->device, stream, m->stage, buf, bytes) != 0 || sgmd_event_record(g->device, m->ev_sent, stream) != 0) return -1;
+    if ((m->used_before && sgmd_stream_wait_event(g->device, stream, m->ev_taken) != 0) ||
+        sgmd_d2d_async(g->device, stream, m->stage, buf, bytes) != 0 || sgmd_event_record(g->device, m->ev_sent, stream) != 0) {
+        pthread_mutex_lock(&g->mu);                                   /* back to the pool: the group frees it */
+        m->next = g->pool[x->rank];
+        g->pool[x->rank] = m;
+        pthread_mutex_unlock(&g->mu);
+        return -1;
+    }
     m->bytes = bytes; m->next = NULL; m->used_before = true;
     pthread_mutex_lock(&g->mu);
     local_queue* q = &g->q[x->rank * g->world + peer];
