@@ -772,6 +772,7 @@ static void launch_aggregate(const AggArgs& a, int blocks, bool pad, int hl, hip
     if constexpr (NN) {
         if (hl == 64 && launch_aggregate_hl<DPL, LPP, 64, NN>(a, blocks, pad, st)) return;
         if (hl == 32 && launch_aggregate_hl<DPL, LPP, 32, NN>(a, blocks, pad, st)) return;
+        if (hl == 16 && launch_aggregate_hl<DPL, LPP, 16, NN>(a, blocks, pad, st)) return;
     }
     launch_aggregate_hl<DPL, LPP, 0, NN>(a, blocks, pad, st);
 }

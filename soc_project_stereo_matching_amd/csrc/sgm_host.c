@@ -623,14 +623,19 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
     }
     /* one frame per launch: the horizontal lines (W-1 serial steps) are the longest chains of the launch -> spread each
      * pixel of those over 32 lanes (2 lines per wave).  64 lanes (SGM_HL=64, one line per wave) measures the same at
-     * KITTI size (0.351 vs 0.349 ms): with one frame the launch is then bound by total VALU issue at ~2 waves per SIMD */
+     * KITTI size (0.351 vs 0.349 ms): with one frame the launch is then bound by total VALU issue at ~2 waves per SIMD.
+     * Batches with 8 lanes per pixel: 16 lanes on the horizontal lines (4 lines per wave: a third fewer instructions per step of
+     * the launch's longest chains for 4 % more instructions in total) -- KITTI 3850 -> 4010 fps through host pointers, aggregation
+     * 1.19 -> 1.16 ms per 8 frames alone; 32 and 64 lanes cost more than they shorten (round 2) */
     {
         const char* e = getenv("SGM_HL");
         const int ok64 = (s->g.Dp % 64 == 0) && (s->g.Dp / 64 == 2 || s->g.Dp / 64 == 4 || s->g.Dp / 64 == 8);
         const int ok32 = (s->g.Dp % 32 == 0) && (s->g.Dp / 32 == 2 || s->g.Dp / 32 == 4 || s->g.Dp / 32 == 8 || s->g.Dp / 32 == 16);
-        int want = (e && *e) ? atoi(e) : (s->batch == 1 ? 32 : 0);
+        int want = (e && *e) ? atoi(e) : (s->batch == 1 ? 32 : (s->g.LPP == 8 ? 16 : 0));
+        const int ok16 = s->g.LPP == 8 && (s->g.Dp / 16 == 2 || s->g.Dp / 16 == 4 || s->g.Dp / 16 == 8 || s->g.Dp / 16 == 16);
         if (want == 64 && !ok64) want = 32;
         if (want == 32 && !ok32) want = 0;
+        if (want == 16 && !ok16) want = 0;
         if (want == s->g.LPP || option->p1 < 0 || s->census_w) want = 0;
         s->g.HL = want;
     }
