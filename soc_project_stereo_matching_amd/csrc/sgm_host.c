@@ -18,7 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define SGM_VERSION_STRING "sgm_mi355x 0.2 (gfx950, hand-written HIP)"
+#define SGM_VERSION_STRING "sgm_mi355x 0.3 (gfx950, hand-written HIP)"
 #define CENSUS_FRONT_SLACK ((size_t)(65535 + SGM_MAX_DISPARITY_RANGE + 8 + 63) / 64 * 64 * 4)   /* >= sgmd_census_slack() for any options */
 
 #define TIMING_RING 64
