@@ -631,7 +631,7 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
         const char* e = getenv("SGM_HL");
         const int ok64 = (s->g.Dp % 64 == 0) && (s->g.Dp / 64 == 2 || s->g.Dp / 64 == 4 || s->g.Dp / 64 == 8);
         const int ok32 = (s->g.Dp % 32 == 0) && (s->g.Dp / 32 == 2 || s->g.Dp / 32 == 4 || s->g.Dp / 32 == 8 || s->g.Dp / 32 == 16);
-        int want = (e && *e) ? atoi(e) : (s->batch == 1 ? 32 : (s->g.LPP == 8 ? 16 : 0));
+        int want = (e && *e) ? atoi(e) : ((s->batch == 1 || s->g.LPP == 16) ? 32 : 16);   /* D > 128 in batches (16 lanes elsewhere): 32, +2 % at 2880x1988 D=256 */
         const int ok16 = s->g.LPP == 8 && (s->g.Dp / 16 == 2 || s->g.Dp / 16 == 4 || s->g.Dp / 16 == 8 || s->g.Dp / 16 == 16);
         if (want == 64 && !ok64) want = 32;
         if (want == 32 && !ok32) want = 0;
