@@ -1,0 +1,73 @@
+"""bench.py without a GPU: what the driver's contract needs from it that can be checked on the CPU -- every workload the default
+line times has reference digests for exactly the frames it will verify (tests/golden/bench_frames.json, made by the compiled
+reference), the defaults finish in minutes, the roofline helper's arithmetic, the frame pool sharding."""
+import json
+import os
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_default_legs_have_reference_digests_for_every_frame_they_check():
+    with open(os.path.join(ROOT, "tests", "golden", "bench_frames.json")) as f:
+        golden = json.load(f)["workloads"]
+    # headline: the 32-frame KITTI pool
+    w, h, d, seed = bench.WORKLOADS["kitti_1242x375_d128_p8"]
+    have = bench.golden_digests("kitti_1242x375_d128_p8")
+    assert all(seed + f in have for f in range(bench.POOL_FRAMES))
+    assert golden["kitti_1242x375_d128_p8"]["w"] == w and golden["kitti_1242x375_d128_p8"]["h"] == h
+    # the other single-GPU configs of the line: (workload, frames per launch, batches verified)
+    for name, B, n in (("cone_450x375_d64_p8", 8, 2), ("cone_450x375_d64_p4", 8, 2), ("middlebury_2880x1988_d256_p8", 2, 2),
+                       ("drivingstereo_1762x800_d192_p8", 2, 2)):
+        seed = bench.WORKLOADS[name][3]
+        have = bench.golden_digests(name)
+        assert all(seed + f in have for f in range(n * B)), name
+    # config 5 as a stream: first and last four of 256 frames
+    seed = bench.WORKLOADS["drivingstereo_1762x800_d192_p8"][3]
+    have = bench.golden_digests("drivingstereo_1762x800_d192_p8")
+    assert all(seed + f in have for f in (0, 1, 2, 3, 252, 253, 254, 255))
+
+
+def test_pool_is_sharded_frame_by_frame_over_the_ranks():
+    from soc_project_stereo_matching_amd.sharding import frames_of_rank
+    for world in (1, 2, 4, 8):
+        shares = [frames_of_rank(bench.POOL_FRAMES, world, r) for r in range(world)]
+        assert sorted(sum(shares, [])) == list(range(bench.POOL_FRAMES))
+        assert all(len(s) == bench.POOL_FRAMES // world for s in shares)
+
+
+def test_roofline_object_arithmetic():
+    counters = {"source_id": bench.source_id(), "file": "x", "kernels": {"k": {"hbm_bytes_per_frame": 500e6, "valu_insts_per_frame": 50e6}}}
+    r = bench.kernel_roofline("k", 1.0, 10, 0.9, 8, counters, 480e6, "note", ref_equiv_bytes_per_frame=2.4e9)
+    assert r["traffic"] == 4_000_000_000 and r["achieved"] == 4000.0 and r["frac"] == 0.5 and not r["traffic_stale"]
+    assert r["algorithmic_frac"] == round(480e6 * 8 / 1e-3 / 1e9 / 8000.0, 4)
+    assert r["valu"]["frac"] == round(50e6 * 8 * 4 / (1024 * 2.4e9 * 1e-3), 4) and r["bound"] == "valu"
+    assert r["reference_dataflow_equiv"]["x_peak"] == 2.4
+    # counters of other kernel sources are reported but not used for the fraction
+    stale = dict(counters, source_id="0000")
+    r = bench.kernel_roofline("k", 1.0, 10, 0.9, 8, stale, 480e6, "note")
+    assert r["traffic_stale"] and r["bytes_used"] == "algorithmic" and r["frac"] == r["algorithmic_frac"]
+
+
+def test_committed_counters_belong_to_the_committed_kernels():
+    """profiles/counters.json is stamped with the hash of csrc/*.hip, *.hpp it was measured on: a kernel change without a fresh
+    counter run would silently turn the driver line's `traffic` into a stale number (bench.py then falls back to algorithmic bytes
+    and says traffic_stale)."""
+    with open(os.path.join(ROOT, "profiles", "counters.json")) as f:
+        doc = json.load(f)
+    assert doc["source_id"] == bench.source_id()
+    for wl in ("kitti_1242x375_d128_p8", "cone_450x375_d64_p8", "drivingstereo_1762x800_d192_p8", "middlebury_2880x1988_d256_p8"):
+        k = doc["workloads"][wl]["kernels"]
+        assert k["sgm_aggregate_k"]["hbm_bytes_per_frame"] > 0 and k["sgm_sum_wta_lr_k"]["valu_insts_per_frame"] > 0
+
+
+def test_defaults_are_the_driver_contract():
+    import argparse  # noqa: F401
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"--gpus", type=int, default=1' in src and '"--steps"' in src and '"--warmup"' in src
+    assert bench.HBM_PEAK_GBS == 8000.0 and bench.PATHS == 8
