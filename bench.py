@@ -831,7 +831,7 @@ def run_frames(args):
             if "workloads" in legs:
                 wl = []
                 for name, wb, wf, ws in (("cone_450x375_d64_p8", 8, 2, 40), ("cone_450x375_d64_p4", 8, 2, 40),
-                                         ("middlebury_2880x1988_d256_p8", 2, 2, 8), ("drivingstereo_1762x800_d192_p8", 2, 3, 24)):
+                                         ("middlebury_2880x1988_d256_p8", 2, 2, 8), ("drivingstereo_1762x800_d192_p8", 8, 2, 8)):
                     try:
                         wl.append(device_resident_leg(S, torch, local_rank, name, wb, wf, ws, 3, honor4=name.endswith("_p4")))
                     except Exception as e:                       # one workload must not take the line down
@@ -839,7 +839,7 @@ def run_frames(args):
                 line["workloads"] = wl
             if "stream" in legs:
                 try:
-                    line["stream"] = stream_leg(S, local_rank, "drivingstereo_1762x800_d192_p8", args.stream_frames, 2, 3)
+                    line["stream"] = stream_leg(S, local_rank, "drivingstereo_1762x800_d192_p8", args.stream_frames, 8, 3)
                 except Exception as e:
                     line["stream"] = {"error": repr(e)}
             if "cpu" in legs and not args.no_cpu_baseline:

@@ -27,7 +27,8 @@ WORKLOADS = {
     "kitti_1242x375_d128_p8": (1242, 375, 128, 0x5EED0002, range(32)),          # BASELINE config 4: a batch of 32 frames
     "cone_450x375_d64_p8": (450, 375, 64, 0x5EED0001, range(16)),
     # BASELINE config 5 is a stream: bench.py pushes 256 distinct frames through and checks the first and the last four
-    "drivingstereo_1762x800_d192_p8": (1762, 800, 192, 0x5EED0005, list(range(4)) + list(range(252, 256))),
+    # (and its device-resident leg runs batches of 8: the first 16 frames)
+    "drivingstereo_1762x800_d192_p8": (1762, 800, 192, 0x5EED0005, list(range(16)) + list(range(252, 256))),
     "middlebury_2880x1988_d256_p8": (2880, 1988, 256, 0x5EED0003, range(4)),
     "uhd_3840x2160_d128_p8": (3840, 2160, 128, 0x5EED0006, range(8)),
     "uhd_3840x2160_d256_p8": (3840, 2160, 256, 0x5EED0007, range(4)),
