@@ -727,7 +727,7 @@ def run_frames(args):
     dev = None
     if "device" in legs:
         dev = device_resident_leg(S, torch, local_rank, args.workload, B, max(1, args.in_flight), max(10, min(args.steps, 80)),
-                                  min(args.warmup, 10), overlap_post=False, cu_split="", honor4=honor4, alone=args.alone)
+                                  min(args.warmup, 10), overlap_post=False, cu_split="", honor4=honor4, alone=bool(args.alone))
         if world > 1:
             t = torch.tensor([dev["fps"]], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -784,6 +784,11 @@ def run_frames(args):
             line["sustained"] = sustained
         if dev:
             line["device_resident"] = dev
+            # the kernels' own quality (one batch in flight, nothing else on the GPU) beside the timed configuration's launch times
+            for key in ("roofline", "roofline_sum_wta"):
+                if line.get(key) and dev.get(key) and dev[key].get("alone"):
+                    line[key]["alone"] = dict(dev[key]["alone"], measured_in="device_resident leg: the same kernel, 8 frames per launch, one "
+                                                                              "instance, nothing else on the GPU")
         if world == 1:
             if "latency" in legs:
                 line.update(single_frame_leg(S, torch, local_rank, args.workload))
@@ -900,10 +905,10 @@ def main():
     ap.add_argument("--cu-split", default=None, metavar="SPEC",
                     help="sgm_set_stage_cus on the bench's instances: stage groups on streams and compute units of their own, e.g. "
                          "'post=0:2,sum=2:8,main=10:22' = first:count CUs of every XCD (count 0: own stream on all CUs)")
-    ap.add_argument("--alone", action="store_true",
-                    help="after the timed region also time the batches with ONE instance and nothing else on the GPU -> roofline.alone "
-                         "(off by default: a kernel trace of the default run then holds the timed configuration only, so rocprofv3's "
-                         "per-kernel average and roofline.avg_launch_ms describe the same launches)")
+    ap.add_argument("--alone", type=int, default=1, choices=[0, 1], nargs="?", const=1,
+                    help="device-resident leg: after its timed region also time the batches with ONE instance and nothing else on the GPU -> "
+                         "device_resident.roofline.alone (the kernel's own quality; in the timed regions other batches share the chip).  "
+                         "On by default; the kernel-trace profile of tools/refresh_profiles.sh runs --legs headline, which has no such launches")
     args = ap.parse_args()
     if args.mode == "tiles":
         # a rank of the tile pipeline keeps ~N + 3 HIP streams busy, some with millisecond-long serial kernels (tile_begin's

@@ -14,4 +14,4 @@ cp $R/gpurun_out/counters.json $R/profiles/counters.json          # so that the 
 # over the timed launches describe nearly the same set; tools/trace_summary.py gives the timed-only mean from the trace.
 rm -rf $R/gpurun_out/prof_stats && rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_stats -o stats --output-format csv -- python3 $R/bench.py --gpus 1 --steps 60 --warmup 2 --legs headline > $R/gpurun_out/bench_under_rocprof.json 2> $R/gpurun_out/prof_stats.log; echo rocprof=$?
 python3 $R/tools/trace_summary.py $R/gpurun_out/prof_stats/stats_kernel_trace.csv $R/gpurun_out/bench_under_rocprof.json > $R/gpurun_out/kernel_trace_summary.json
-cd $R && sleep 10 && python bench.py --gpus 1 --steps 20 --warmup 5 --alone > gpurun_out/bench.json 2> gpurun_out/bench.err; echo bench=$?
+cd $R && sleep 10 && python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo bench=$?
