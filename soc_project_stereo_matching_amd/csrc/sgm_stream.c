@@ -4,22 +4,25 @@
  * images in, host floats out).
  *
  *   sgm_stream [--width W] [--height H] [--disparities D] [--batch B] [--instances N] [--seconds S] [--frames F] [--seed X]
- *              [--pageable] [--blocking]
+ *              [--pageable] [--blocking] [--numa-node K]
  *
  *   default      N instances, one host thread each, batches of B frames through sgm_reset + sgm_match_async + sgm_match_wait on
  *                page-locked buffers (sgm_host_alloc) for S seconds: the pipelined throughput path (bench.py's headline, in C)
  *   --blocking   one thread, one frame per call through sgm_compute (SGM_Reset + SGM_Match) on malloc'd buffers: the reference
  *                contract as it stands
  *   --pageable   malloc'd caller buffers instead of page-locked ones (staged by the library)
+ *   --numa-node K  run (and allocate) on the CPUs of NUMA node K -- the node the GPU hangs off (/sys/bus/pci/devices/<bdf>/numa_node):
+ *                the host threads spin in stream synchronisation and feed 11 GB/s over PCIe; bench.py pins itself the same way
  *
  * Frames are the synthetic pairs of SURVEY.md 8(d) (SGM_SynthPair, seed + frame index), F distinct ones cycled.  Prints one JSON
  * line: frames, seconds, fps, Mdisp/s and an FNV-1a hash of the disparity map of frame 0 (tests/test_gpu_stream_c.py compares
  * it with the oracle's map hashed the same way).
  */
-#define _POSIX_C_SOURCE 200809L
+#define _GNU_SOURCE
 #include "../../include/sgm_mi355x.h"
 
 #include <pthread.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -30,6 +33,26 @@ static double now_s(void)
     struct timespec t;
     clock_gettime(CLOCK_MONOTONIC, &t);
     return t.tv_sec + t.tv_nsec * 1e-9;
+}
+
+/* restrict the process to the CPUs of a NUMA node (best effort: false if sysfs does not list them) */
+static int pin_to_node(int node)
+{
+    char path[96], buf[4096];
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE* f = fopen(path, "r");
+    if (!f || !fgets(buf, sizeof buf, f)) { if (f) fclose(f); return 0; }
+    fclose(f);
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (char* tok = strtok(buf, ",\n"); tok; tok = strtok(NULL, ",\n")) {
+        int a = 0, b = 0;
+        const int n = sscanf(tok, "%d-%d", &a, &b);
+        if (n < 1) continue;
+        if (n == 1) b = a;
+        for (int c = a; c <= b && c < CPU_SETSIZE; ++c) CPU_SET(c, &set);
+    }
+    return sched_setaffinity(0, sizeof set, &set) == 0;
 }
 
 static unsigned long long fnv1a(const void* p, size_t n)
@@ -84,7 +107,7 @@ static void* worker_main(void* p)
 
 int main(int argc, char** argv)
 {
-    int W = 1242, H = 375, D = 128, B = 8, N = 4, F = 32, pageable = 0, blocking = 0;
+    int W = 1242, H = 375, D = 128, B = 8, N = 4, F = 32, pageable = 0, blocking = 0, node = -1;
     double seconds = 2.0;
     unsigned seed = 0x5EED0002u;
     for (int i = 1; i < argc; ++i) {
@@ -99,10 +122,12 @@ int main(int argc, char** argv)
         else if (v && !strcmp(a, "--instances")) N = atoi(argv[++i]);
         else if (v && !strcmp(a, "--frames")) F = atoi(argv[++i]);
         else if (v && !strcmp(a, "--seconds")) seconds = atof(argv[++i]);
+        else if (v && !strcmp(a, "--numa-node")) node = atoi(argv[++i]);
         else if (v && !strcmp(a, "--seed")) seed = (unsigned)strtoul(argv[++i], NULL, 0);
         else { fprintf(stderr, "sgm_stream: unknown argument %s (see the header of sgm_stream.c)\n", a); return 2; }
     }
     if (W < 1 || H < 1 || D < 1 || B < 1 || N < 1 || N > 16 || F < 1) return 2;
+    if (node >= 0 && !pin_to_node(node)) fprintf(stderr, "sgm_stream: could not pin to NUMA node %d (continuing unpinned)\n", node);
     SGMOption opt;
     memset(&opt, 0, sizeof opt);                       /* main.c:48-65 with max_disparity = D */
     opt.num_paths = 8; opt.min_disparity = 0; opt.max_disparity = (uint16_t)D;
