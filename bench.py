@@ -55,7 +55,11 @@ WORKLOADS = {
     "uhd_3840x2160_d256_p8": (3840, 2160, 256, 0x5EED0007),
     # BASELINE config 1's "4 paths": the library's extension (sgm_set_honor_num_paths); digests are oracle-made
     "cone_450x375_d64_p4": (450, 375, 64, 0x5EED0001),
+    # throughput with speckle removal on AND off -- the KITTI frames with is_remove_speckles = false (main.c:60 flipped),
+    # reference digests of their own
+    "kitti_1242x375_d128_p8_nospeckle": (1242, 375, 128, 0x5EED0002),
 }
+SPECKLE_OFF = "_nospeckle"
 POOL_FRAMES = 32               # BASELINE config 4: a batch of 32 KITTI frames, sharded over the ranks frame by frame
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
 N_SIMD = 1024                  # 256 CUs x 4 SIMDs
@@ -165,7 +169,8 @@ def load_counters(workload):
         return None
     with open(path) as f:
         doc = json.load(f)
-    wl = doc.get("workloads", {}).get(workload)
+    # the speckle-off variant runs the same aggregation / cost-sum launches on the same frames
+    wl = doc.get("workloads", {}).get(workload[:-len(SPECKLE_OFF)] if workload.endswith(SPECKLE_OFF) else workload)
     if wl is None:
         return None
     return {"source_id": doc.get("source_id"), "file": "profiles/counters.json", **wl}
@@ -439,7 +444,7 @@ def device_resident_leg(S, torch, device, workload, B, n_inst, steps, warmup, ov
     own instances, one host thread; every frame of the last batch of each instance verified."""
     w, h, d, seed = WORKLOADS[workload]
     npaths = paths_of(workload)
-    opt = S.default_option(d, num_paths=npaths)
+    opt = S.default_option(d, num_paths=npaths, is_remove_speckles=not workload.endswith(SPECKLE_OFF))
     insts = [S.SGMInstance(device, batch=B) for _ in range(n_inst)]
     for i in insts:
         if honor4:
@@ -510,7 +515,7 @@ def device_resident_leg(S, torch, device, workload, B, n_inst, steps, warmup, ov
     del frames, outs
     torch.cuda.empty_cache()
     n_fr = steps * B
-    res = {"workload": workload, "width": w, "height": h, "disparity_range": d, "paths": npaths,
+    res = {"workload": workload, "width": w, "height": h, "disparity_range": d, "paths": npaths, "speckle_removal": bool(opt.is_remove_speckles),
            "entry": "sgm_reset + sgm_match_device (frames resident in HBM: kernels only)",
            "fps": round(n_fr / elapsed, 2), "value": round(w * h * d * npaths * n_fr / elapsed / 1e6, 1), "unit": "Mdisp/s",
            "ms_per_frame": round(elapsed / n_fr * 1e3, 4), "ms_per_step": round(elapsed / steps * 1e3, 4), "steps": steps,
@@ -661,7 +666,7 @@ def run_frames(args):
     w, h, d, seed = WORKLOADS[args.workload]
     npaths = paths_of(args.workload)
     honor4 = npaths == 4
-    opt = S.default_option(d, num_paths=npaths)
+    opt = S.default_option(d, num_paths=npaths, is_remove_speckles=not args.workload.endswith(SPECKLE_OFF))
     B = max(1, args.batch)
     n_host = max(1, args.host_instances)
     digests = golden_digests(args.workload)
@@ -746,7 +751,7 @@ def run_frames(args):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u16 integer min-plus (f32 sub-pixel tail)", "data": "synthetic",
             "config": {"workload": args.workload, "mode": "frames", "width": w, "height": h, "disparity_range": d, "paths": npaths,
-                       "stages": "census+cost+aggregate8+wta+lrcheck+speckle+median" if npaths == 8 else "census+cost+aggregate4+wta+lrcheck+speckle+median",
+                       "stages": f"census+cost+aggregate{npaths}+wta+lrcheck+" + ("speckle+" if opt.is_remove_speckles else "") + "median",
                        "entry": "sgm_reset + sgm_match_async + sgm_match_wait on page-locked host buffers: H2D + kernels + D2H per step "
                                 "(the reference's SGM_Reset + SGM_Match contract, SemiGlobalMatching.c:77-78,122)",
                        "frames_per_step": B * n_host, "frames_per_launch": B, "frames_per_gpu": args.steps * B * n_host,
@@ -836,7 +841,8 @@ def run_frames(args):
             if "workloads" in legs:
                 wl = []
                 for name, wb, wf, ws in (("cone_450x375_d64_p8", 8, 2, 40), ("cone_450x375_d64_p4", 8, 2, 40),
-                                         ("middlebury_2880x1988_d256_p8", 2, 2, 8), ("drivingstereo_1762x800_d192_p8", 8, 2, 8)):
+                                         ("middlebury_2880x1988_d256_p8", 2, 2, 8), ("drivingstereo_1762x800_d192_p8", 8, 2, 8),
+                                         ("kitti_1242x375_d128_p8_nospeckle", 8, 2, 20)):
                     try:
                         wl.append(device_resident_leg(S, torch, local_rank, name, wb, wf, ws, 3, honor4=name.endswith("_p4")))
                     except Exception as e:                       # one workload must not take the line down

@@ -36,8 +36,12 @@ WORKLOADS = {
     # 4-path extension is defined by oracle/sgm_oracle.c alone, so THESE digests are oracle-made: "4-path parity unpinned by the
     # reference" -- they pin the bench's timed frames to the CPU restatement, nothing more.
     "cone_450x375_d64_p4": (450, 375, 64, 0x5EED0001, range(16)),
+    # throughput is reported with speckle removal on AND off; the same KITTI frames with is_remove_speckles = false
+    # (main.c:60 flipped), so that the speckle-off rate is a verified one too
+    "kitti_1242x375_d128_p8_nospeckle": (1242, 375, 128, 0x5EED0002, range(16)),
 }
 ORACLE_MADE = {"cone_450x375_d64_p4"}
+SPECKLE_OFF = {"kitti_1242x375_d128_p8_nospeckle"}
 KEEP = ["disp_l", "disp_r", "after_lr", "after_speckle", "final"]
 
 
@@ -60,7 +64,7 @@ def one_frame(job):
     assert ref is not None, f"oracle/build_ref.sh {w} {h} {d} first"
     left, right = Oracle().synth_pair(w, h, d, seed)
     t0 = time.time()
-    st = ref.run(left, right, default_option(d))
+    st = ref.run(left, right, default_option(d, is_remove_speckles=False) if name in SPECKLE_OFF else default_option(d))
     return name, seed, {"sha256": {n: sha(st[n]) for n in KEEP}, "sha256_inputs": {"left": sha(left), "right": sha(right)},
                         "invalid_final": int(np.isinf(st["final"]).sum()), "oob_dropped": ref.oob_count(),
                         "reference_seconds": round(time.time() - t0, 1)}
@@ -78,7 +82,8 @@ def main():
         w, h, d, seed, frames = WORKLOADS[n]
         old = {} if force else doc["workloads"].get(n, {}).get("frames", {})
         doc["workloads"][n] = {"w": w, "h": h, "d": d, "first_seed": seed,
-                               "option": "main.c:48-65 with max_disparity = D" + (", num_paths = 4 honoured" if n in ORACLE_MADE else ""),
+                               "option": "main.c:48-65 with max_disparity = D" + (", num_paths = 4 honoured" if n in ORACLE_MADE else "")
+                                         + (", is_remove_speckles = false" if n in SPECKLE_OFF else ""),
                                "frames": dict(old)}
         jobs += [(n, w, h, d, seed + k) for k in frames if str(seed + k) not in old]     # only what is missing (--force: all)
     jobs.sort(key=lambda j: -(j[1] * j[2] * j[3]))            # big frames first

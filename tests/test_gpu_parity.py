@@ -503,6 +503,30 @@ def test_batched_fast_path_kitti_against_reference_digests():
         i.close()
 
 
+def test_batched_fast_path_kitti_without_speckle_removal():
+    """SURVEY.md 8(d) asks for throughput with speckle removal on and off: the speckle-off rate in bench.py's line is checked against
+    these digests -- the reference's own C on the same 16 KITTI frames with is_remove_speckles = false (main.c:60 flipped)."""
+    import torch
+    import soc_project_stereo_matching_amd as S
+    wl = _bench_frames("kitti_1242x375_d128_p8_nospeckle")
+    assert wl is not None and len(wl["frames"]) >= 16
+    w, h, d, seed, B = wl["w"], wl["h"], wl["d"], wl["first_seed"], 8
+    opt = S.default_option(d, is_remove_speckles=False)
+    inst = S.SGMInstance(0, batch=B)
+    inst.keep_stages(False)
+    out = torch.empty((B, h, w), dtype=torch.float32, device="cuda")
+    for k in range(2):
+        ps = [S.synth_pair(w, h, d, seed + k * B + j) for j in range(B)]
+        l, r = torch.from_numpy(np.stack([p[0] for p in ps])).cuda(), torch.from_numpy(np.stack([p[1] for p in ps])).cuda()
+        assert inst.reset(w, h, opt) and inst.match_device(l.data_ptr(), r.data_ptr(), out.data_ptr()) and inst.synchronize()
+        got = out.cpu().numpy()
+        for j in range(B):
+            e = wl["frames"][str(seed + k * B + j)]["sha256"]
+            assert e["after_speckle"] == e["after_lr"]                    # the reference skipped the stage
+            assert sha(got[j]) == e["final"], f"batch {k} frame {j}: final"
+    inst.close()
+
+
 @pytest.mark.parametrize("shape", [(600, 140, 0, 100, 8), (333, 150, 2, 66, 8), (500, 130, 0, 192, 4), (420, 260, 0, 256, 4)])
 def test_batched_fast_path_padded_disparity_ranges(oracle, shape):
     """The same fast path (batch, keep_stages off, two instances in flight) where D is not the padded stride (D = 100
