@@ -23,7 +23,7 @@ def test_default_legs_have_reference_digests_for_every_frame_they_check():
     assert golden["kitti_1242x375_d128_p8"]["w"] == w and golden["kitti_1242x375_d128_p8"]["h"] == h
     # the other single-GPU configs of the line: (workload, frames per launch, batches verified)
     for name, B, n in (("cone_450x375_d64_p8", 8, 2), ("cone_450x375_d64_p4", 8, 2), ("middlebury_2880x1988_d256_p8", 2, 2),
-                       ("drivingstereo_1762x800_d192_p8", 8, 2)):
+                       ("drivingstereo_1762x800_d192_p8", 8, 2), ("kitti_1242x375_d128_p8_nospeckle", 8, 2)):
         seed = bench.WORKLOADS[name][3]
         have = bench.golden_digests(name)
         assert all(seed + f in have for f in range(n * B)), name
