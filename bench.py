@@ -97,6 +97,17 @@ def digest(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+def host_cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def cpu_baseline(w, h, d, seed, budget_s=25.0):
     """The reference's C (oracle/_ref, built from /root/reference in the build container) timed on one
     host core on a bounded sample of the same workload; falls back to our C port of it."""
@@ -130,7 +141,7 @@ def cpu_baseline(w, h, d, seed, budget_s=25.0):
     return {"value": round(w * h * d * PATHS / t / 1e6, 2), "unit": "Mdisp/s", "cores": 1, "kind": kind,
             "sample": f"{k} frame(s) of {w}x{h} D={d} 8 paths, SGM_Reset+SGM_Match each, median; "
                       f"{t:.2f} s/frame = {1.0 / t:.3f} fps on 1 of {os.cpu_count()} host cores",
-            "fps": round(1.0 / t, 4)}
+            "fps": round(1.0 / t, 4), "host_cpu": host_cpu_model(), "host_cores": os.cpu_count()}
 
 
 def cpu_baseline_all_cores(w, h, d, seed, max_procs=16, timeout_s=90.0):
