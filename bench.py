@@ -604,6 +604,38 @@ def blocking_leg(S, w, h, d, opt, pairs, seeds, digests, budget_s=2.0):
             "verified": (digest(out) == digests[sd]) if sd in digests else None}
 
 
+def blocking_pinned_leg(S, device, w, h, opt, pairs, seeds, digests, budget_s=1.0):
+    """One frame at a time as above, but the caller keeps its images and its result in page-locked memory (sgm_host_alloc): no staging
+    copies, the DMA engines work on the caller's buffers.  The frame is put into the page-locked arrays outside the timed call (a
+    camera driver would have captured it there)."""
+    i = S.SGMInstance(device)
+    try:
+        if not i.reset(w, h, opt):
+            return {"error": "sgm_reset failed"}
+        L, R, O = i.host_array((h, w), np.uint8), i.host_array((h, w), np.uint8), i.host_array((h, w), np.float32)
+        n, t_sum = 0, 0.0
+        t_begin = time.perf_counter()
+        while n < 400 and time.perf_counter() - t_begin < budget_s:
+            L[...], R[...] = pairs[n % len(pairs)]
+            t0 = time.perf_counter()
+            ok = i.reset(w, h, opt) and i.match_async(L, R, O) and i.match_wait()
+            dt = time.perf_counter() - t0
+            if not ok:
+                return {"error": "sgm_match_async / sgm_match_wait failed"}
+            if n >= 2:
+                t_sum += dt
+            n += 1
+        if n <= 2:
+            return {"error": "too few frames"}
+        ms = t_sum / (n - 2) * 1e3
+        sd = seeds[(n - 1) % len(pairs)]
+        return {"ms_per_frame": round(ms, 4), "fps": round(1e3 / ms, 1), "frames": n - 2,
+                "entry": "sgm_reset + sgm_match_async + sgm_match_wait, one frame per call, caller buffers from sgm_host_alloc",
+                "verified": (digest(O) == digests[sd]) if sd in digests else None}
+    finally:
+        i.close()
+
+
 def stream_leg(S, device, workload, n_frames, B, n_inst):
     """BASELINE config 5 as a stream: n_frames DISTINCT frames (seed = first + f) through the host-pointer pipeline, every input
     and output in its own page-locked buffer; sustained rate over the whole stream; the first and the last four frames verified."""
@@ -811,7 +843,8 @@ def run_frames(args):
             if "host" in legs:
                 pairs = [pair_of[f] for f in sorted(pair_of)][:16]
                 sds = [seed + f for f in sorted(pair_of)][:16]
-                hb = {"blocking_single_frame": blocking_leg(S, w, h, d, opt, pairs, sds, digests)}
+                hb = {"blocking_single_frame": blocking_leg(S, w, h, d, opt, pairs, sds, digests),
+                      "blocking_single_frame_pinned": blocking_pinned_leg(S, local_rank, w, h, opt, pairs, sds, digests)}
                 # the same pipeline with PAGEABLE caller buffers (staged through the instances' own pinned buffers)
                 pg = [S.SGMInstance(local_rank, batch=B) for _ in range(n_host)]
                 try:
