@@ -3,6 +3,7 @@
 // kernels for negative P1 live in sgm_aggregate_generic.hip (their own translation unit: parallel build)
 bool sgmd_aggregate_launch_generic(int lpp, int dpl, const AggArgs* a, int blocks, int pad, hipStream_t st);
 bool sgmd_aggregate_launch_volume(int dpl, const AggArgs* a, int blocks, int pad, hipStream_t st);
+bool sgmd_aggregate_launch_anom(int dp, const AggArgs* a, int pad, int from_volume, hipStream_t st);
 // ... and those with the shortcuts for ordinary penalties in sgm_aggregate_fast.hip
 bool sgmd_aggregate_launch_fast(int lpp, int dpl, const AggArgs* a, int blocks, int pad, int hl, hipStream_t st);
 
@@ -28,8 +29,8 @@ static int aggregate_any(int ord, void* stream, const sgmd_geom* g, const sgmd_p
     a.p1 = paths->p1;
     a.ndirs = paths->ndirs;
     a.ghost_zero = paths->ghost_zero;
-    // SGM_DIR_MASK (diagnostics only: wrong results): run a subset of the directions, to time them apart
-    static const int debug_mask = getenv("SGM_DIR_MASK") ? (int)strtol(getenv("SGM_DIR_MASK"), nullptr, 0) : 0xFF;
+    // SGM_DIR_MASK (diagnostics only: wrong results): run a subset of the directions, to time them apart; bit 8 = the anomalous lines
+    static const int debug_mask = getenv("SGM_DIR_MASK") ? (int)strtol(getenv("SGM_DIR_MASK"), nullptr, 0) : 0x1FF;
     int blocks = 0;
     for (int d = 0; d < 8; ++d) {
         a.dx[d] = paths->dx[d]; a.dy[d] = paths->dy[d]; a.anom_line[d] = paths->anom_line[d];
@@ -41,9 +42,24 @@ static int aggregate_any(int ord, void* stream, const sgmd_geom* g, const sgmd_p
         }
     }
     a.block_begin[8] = blocks;
-    if (debug_mask != 0xFF) a.run_anom = 0;
-    if (a.run_anom) blocks += 4;                       // one extra wave per diagonal direction: its anomalous line
+    if (!(debug_mask & 0x100)) a.run_anom = 0;
+    const bool pad = (g->D != g->Dp);
+    hipStream_t st = (hipStream_t)stream;
+    a.strips = 1;
+    // The anomalous line of every diagonal direction (one wave each): with the kernels of the non-negative-P1 step the FIRST four
+    // blocks of every frame of the regular lines' launch; otherwise (negative P1, cost volume: the generic step, whose registers
+    // would set the occupancy of the whole kernel) or where no regular line is asked for, a small launch of its own in front.
+    const bool nn_kernels = !cost && a.p1 >= 0;
+    a.anom_inline = (a.run_anom && nn_kernels && blocks > 0) ? 1 : 0;
+    if (a.run_anom && !a.anom_inline) {
+        if (!sgmd_aggregate_launch_anom(g->Dp, &a, pad ? 1 : 0, cost ? 1 : 0, st)) {
+            fprintf(stderr, "sgm_mi355x: no anomalous-line kernel for a cell of %d disparities\n", g->Dp);
+            return -1;
+        }
+        HIP_TRY(hipGetLastError());
+    }
     if (blocks == 0) return 0;
+    if (a.anom_inline) blocks += 4;
     // XCD-aware numbering for 2 or 4 frames per launch (sgm_aggregate_k): each of a frame's 8 / B XCDs takes a contiguous strip of
     // every direction; the grid is 8 x the longest per-XCD list.  Measured (tools/fetch_probe.sh): census reads of the launch
     // 4.07 -> 1.06 GB per frame at 2880x1988 D=256, 0.34 -> 0.12 GB at 1762x800 D=192.  Not for a single frame: its launch is
@@ -57,7 +73,7 @@ static int aggregate_any(int ord, void* stream, const sgmd_geom* g, const sgmd_p
         for (int sub = 0; sub < a.strips; ++sub) {
             int t = 0;
             for (int d = 0; d <= 8; ++d) {
-                const int n = (d < 8 ? a.block_begin[d + 1] - a.block_begin[d] : (a.run_anom ? 4 : 0));
+                const int n = (d < 8 ? a.block_begin[d + 1] - a.block_begin[d] : (a.anom_inline ? 4 : 0));
                 t += (sub + 1) * n / a.strips - sub * n / a.strips;
             }
             if (t > longest) longest = t;
@@ -65,8 +81,6 @@ static int aggregate_any(int ord, void* stream, const sgmd_geom* g, const sgmd_p
         blocks = 8 * longest;
     } else
         blocks *= g->B;                                // every frame of the batch in the same launch
-    const bool pad = (g->D != g->Dp);
-    hipStream_t st = (hipStream_t)stream;
     bool launched;
     if (cost)           launched = sgmd_aggregate_launch_volume(g->DPL, &a, blocks, pad ? 1 : 0, st);
     else if (a.p1 >= 0) {

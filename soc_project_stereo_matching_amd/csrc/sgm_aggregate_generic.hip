@@ -33,3 +33,40 @@ bool sgmd_aggregate_launch_volume(int dpl, const AggArgs* a, int blocks, int pad
 {
     return launch_aggregate_vol_key(dpl, *a, blocks, pad != 0, st);
 }
+
+// ... and the four anomalous diagonal lines of every frame as a launch of their own (sgm_aggregate_anom_k; the kernels of the
+// non-negative-P1 step carry them inside their own launch): one instantiation per cell width and step
+template <int DPL, int LPP, int NN, bool VOL>
+static void launch_aggregate_anom_one(const AggArgs& a, bool pad, hipStream_t st)
+{
+    const dim3 grid(4 * a.B), block(64);
+    if (pad) hipLaunchKernelGGL((sgm_aggregate_anom_k<DPL, true, LPP, NN, VOL>), grid, block, 0, st, a);
+    else     hipLaunchKernelGGL((sgm_aggregate_anom_k<DPL, false, LPP, NN, VOL>), grid, block, 0, st, a);
+}
+// dp = disparities per cell (Dp); nn = the non-negative-P1 step may be used (never with a cost volume)
+static bool launch_aggregate_anom(int dp, bool nn, bool from_volume, const AggArgs& a, bool pad, hipStream_t st)
+{
+#define SGM_ANOM_CASES(NN, VOL, L)                                                                             \
+    switch (dp) {                                                                                              \
+    case 32:  launch_aggregate_anom_one<L(32)::dpl, L(32)::lpp, NN, VOL>(a, pad, st); return true;             \
+    case 64:  launch_aggregate_anom_one<L(64)::dpl, L(64)::lpp, NN, VOL>(a, pad, st); return true;             \
+    case 128: launch_aggregate_anom_one<L(128)::dpl, L(128)::lpp, NN, VOL>(a, pad, st); return true;           \
+    case 192: launch_aggregate_anom_one<L(192)::dpl, L(192)::lpp, NN, VOL>(a, pad, st); return true;           \
+    case 256: launch_aggregate_anom_one<L(256)::dpl, L(256)::lpp, NN, VOL>(a, pad, st); return true;           \
+    case 512: launch_aggregate_anom_one<L(512)::dpl, L(512)::lpp, NN, VOL>(a, pad, st); return true;           \
+    default: return false;                                                                                     \
+    }
+#define SGM_ANOM_WIDE(dp) anom_layout<dp>
+#define SGM_ANOM_16(dp) anom_layout16<dp>
+    if (from_volume) { SGM_ANOM_CASES(0, true, SGM_ANOM_16) }
+    if (nn) { SGM_ANOM_CASES(1, false, SGM_ANOM_WIDE) }
+    SGM_ANOM_CASES(0, false, SGM_ANOM_16)
+#undef SGM_ANOM_CASES
+#undef SGM_ANOM_WIDE
+#undef SGM_ANOM_16
+}
+
+bool sgmd_aggregate_launch_anom(int dp, const AggArgs* a, int pad, int from_volume, hipStream_t st)
+{
+    return launch_aggregate_anom(dp, a->p1 >= 0 && !from_volume, from_volume != 0, *a, pad != 0, st);
+}

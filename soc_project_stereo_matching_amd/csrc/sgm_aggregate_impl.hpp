@@ -4,6 +4,9 @@
 #ifndef SGM_AGG_PF
 #define SGM_AGG_PF 2      // steps of census words / grey values a wave keeps in flight (8- and 16-lane lines); 3 measured no faster
 #endif
+#ifndef SGM_ANOM_PF
+#define SGM_ANOM_PF 4     // ... and for the anomalous diagonal lines (a kernel of their own: registers are no concern there)
+#endif
 #ifndef SGM_AGG_PF_HL
 #define SGM_AGG_PF_HL 4   // the same for the 32- / 64-lane horizontal lines of a single frame (the launch's critical chain)
 #endif
@@ -34,6 +37,7 @@ struct AggArgs {
     int W, H, D, Dp;
     int row_begin, row_end;     // rows of the frame this launch covers (a row tile of a multi-GPU run; [0,H) normally)
     int run_anom;               // 1: also run the four anomalous diagonal lines (whole frame)
+    int anom_inline;            // 1: ... as the FIRST four blocks of every frame of the regular lines' launch (sgm_aggregate_k); 0: sgm_aggregate_anom_k
     int B;                      // frames per launch; frame f uses img/census + f*W*H, planes + f*8*plane_bytes, extras + f*4*H*Dp
     int p1;
     int ndirs;
@@ -548,10 +552,11 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
 // also visited by regular lines), and it zeroes the cells no line visits (W >= H: the track it
 // should have taken).  One wave per diagonal direction; all four DPP rows compute the same line,
 // row 0 stores.
-template <int DPL, bool PAD, int LPP, bool VOL = false>
+template <int DPL, bool PAD, int LPP, int NN, bool VOL = false>
 static __device__ __forceinline__ void agg_anomalous(const AggArgs& a, const AggFrame& fr, const unsigned short* lut_s,
-                                                     int dir)
+                                                     const unsigned* lut32_s, int dir)
 {
+    static_assert(!(NN && VOL), "the volume-fed lines run the generic step");
     constexpr int NP = DPL / 2;
     constexpr int NW = (DPL + 3) / 4;
     const int lane = threadIdx.x;
@@ -627,38 +632,153 @@ static __device__ __forceinline__ void agg_anomalous(const AggArgs& a, const Agg
         ghost_zero(0);
     }
     const us2 p1v = splat((unsigned)a.p1);
-    bool dead = false;
-    for (int k = 1; k <= nsteps; ++k) {
-        if (!dead) {
-            const bool not_last = fwd ? (row < H - 1) : (row > 0);
-            if (col == W - 1 && not_last)      { p = (long long)(row + s) * W;           col = 0; }       // ref :297-303
-            else if (col == 0 && not_last)     { p = (long long)(row + s) * W + (W - 1); col = W - 1; }   // ref :304-310
-            else                               { p += diag_step; }
-            row = (row + s) & 0xFFFF;
-            col = (col + col_step) & 0xFFFF;
-            if (p < 0 || p >= npx) dead = true;                            // Q6: the line ends
+    // The walk (ref :281-323: positions only) does not depend on the path costs, so it runs PF steps ahead of them and the loads
+    // of a step are in flight while the steps before it compute -- as on the regular lines.  Without that every step waited for its
+    // own image byte and census words (374 dependent round trips at KITTI size: 0.3 ms -- the longest wave of a single frame's
+    // aggregation, and the tail of a batch's).
+    constexpr int PF = (DPL >= 12) ? 2 : SGM_ANOM_PF;                      // wide lanes: the ring must not outgrow the regular lines' registers
+    int pc = line;                                                         // the TRUE column of p (the walk's own `col` runs one off, Q5)
+    auto advance = [&]() {
+        const bool not_last = fwd ? (row < H - 1) : (row > 0);
+        if (col == W - 1 && not_last)      { p = (long long)(row + s) * W;           col = 0;     pc = 0; }       // ref :297-303
+        else if (col == 0 && not_last)     { p = (long long)(row + s) * W + (W - 1); col = W - 1; pc = W - 1; }   // ref :304-310
+        else {
+            p += diag_step;
+            pc += col_step;                                                // diag_step = +-(W +- 1): the column moves by +-1 ...
+            if (pc >= W) pc -= W;                                          // ... and runs over the row end into the neighbouring row
+            if (pc < 0) pc += W;
         }
-        if (!dead) {                                                       // uniform (all rows walk the same line)
-            CellVec<DPL> packed;
-            CensusVec<DPL> cv;
-            us2 C[NP];
-            const int g = fr.img[p];
-            if constexpr (VOL) {
-                load_volume<DPL>(fr.cost + (size_t)p * Dp + lane_off, cv);
-                volume_costs<DPL>(cv, C);
-            } else {
-                load_census<DPL>(fr.census_r + (p - back), cv);
-                census_costs<DPL>(fr.census_l[p], cv, (int)(p % W) - lim_bias, true, C);
-            }
-            const int dg = g > g_prev ? g - g_prev : g_prev - g;
-            min_prev = agg_step<DPL, PAD, LPP>(C, Lp, min_prev, lut_s[dg], p1v, padmask, first_lane, last_lane, packed);
-            g_prev = g;
-            if (store_ok) store_cells<DPL>(extras + (size_t)k * Dp, packed);
+        row = (row + s) & 0xFFFF;
+        col = (col + col_step) & 0xFFFF;
+    };
+    // Q6: the line may leave the image before its H - 1 steps are done and ends there.  Where, is found by walking it once without
+    // the costs (a few scalar instructions per step), so that the loops below have no end-of-line test -- and no load behind one:
+    // hipcc merges s_waitcnt counts over all control-flow paths, a conditional load makes it wait for (nearly) everything in
+    // flight at every step, ring or no ring.
+    int n_live = nsteps;
+    {
+        const long long p0 = p;
+        const int row0 = row, col0 = col;
+        for (int k = 1; k <= nsteps; ++k) {
+            advance();
+            if (p < 0 || p >= npx) { n_live = k - 1; break; }
         }
-        ghost_zero(k);
+        p = p0; row = row0; col = col0; pc = line;
     }
+    CensusVec<DPL> cb[PF];
+    unsigned clb[PF];
+    uint8_t gb[PF];                                                        // bytes, widened at use (see agg_regular)
+    int limb[PF];
+    // The position is the same in every lane, so the image byte and the census-left word would be SCALAR loads -- which return out
+    // of order and can only be waited for all at once (lgkmcnt(0)): every step would wait for the loads the step before it has
+    // just issued (measured: 0.48 us per step).  An opaque zero in a vector register makes them vector loads.
+    unsigned vzero;
+    asm("v_mov_b32 %0, 0" : "=v"(vzero));
+    auto fetch = [&](int u) {
+        const long long pv = p + vzero;
+        gb[u] = fr.img[pv];
+        if constexpr (VOL) {
+            load_volume<DPL>(fr.cost + (size_t)p * Dp + lane_off, cb[u]);
+            clb[u] = 0;
+        } else {
+            load_census<DPL>(fr.census_r + (p - back), cb[u]);
+            clb[u] = fr.census_l[pv];
+        }
+        limb[u] = pc - lim_bias;
+    };
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+        gb[u] = 0; clb[u] = 0; limb[u] = 0;
+#pragma unroll
+        for (int i = 0; i < DPL; ++i) cb[u].r[i] = 0;
+        if (1 + u <= n_live) {
+            advance();
+            fetch(u);
+        }
+    }
+    unsigned sent[2] = {0x00FF00FFu, 0x00FF00FFu};                         // agg_step_nn's carried sentinel registers
+    if constexpr (NN) min_prev |= min_prev << 16;                          // ... and its packed minimum
+    auto step = [&](int u, int k, bool refill) {
+        const int g = (int)gb[u];
+        const unsigned dg = __builtin_amdgcn_sad_u8((unsigned)g, (unsigned)g_prev, 0u);
+        CellVec<DPL> packed;
+        if constexpr (NN) {
+            min_prev = agg_step_nn<DPL, PAD, LPP, false>(clb[u], cb[u], limb[u], __any(limb[u] < DPL - 1) != 0, Lp, min_prev, lut32_s[dg],
+                                                         p1v, padmask, first_lane, last_lane, sent, packed);
+            if (refill) {                                                  // the slot's census words are consumed now
+                advance();
+                fetch(u);
+            }
+        } else {
+            us2 C[NP];
+            if constexpr (VOL) volume_costs<DPL>(cb[u], C);
+            else census_costs<DPL>(clb[u], cb[u], limb[u], true, C);       // consume the slot, then refill it
+            if (refill) {
+                advance();
+                fetch(u);
+            }
+            min_prev = agg_step<DPL, PAD, LPP>(C, Lp, min_prev, lut_s[dg], p1v, padmask, first_lane, last_lane, packed);
+        }
+        g_prev = g;
+        if (store_ok) store_cells<DPL>(extras + (size_t)k * Dp, packed);
+        ghost_zero(k);
+    };
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0): the prologue's loads, once (see agg_regular)
+    int k0 = 1;
+    for (; k0 + 2 * PF - 1 <= n_live; k0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) step(u, k0 + u, true);
+    }
+    for (; k0 <= n_live; k0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u)
+            if (k0 + u <= n_live) step(u, k0 + u, k0 + u + PF <= n_live);
+    }
+    for (int k = n_live + 1; k <= nsteps; ++k) ghost_zero(k);               // the cells the line should have visited (W >= H)
 }
 
+// Lane layout of an anomalous line for a cell of DP disparities: with the non-negative-P1 step the whole wave works on the one
+// line where that leaves an even number >= 2 of disparities per lane (the shortest step, as on the horizontal lines of a single
+// frame); the generic step keeps 16 lanes per pixel.
+template <int DP> struct anom_layout   { static constexpr int lpp = (DP % 128 == 0) ? 64 : (DP == 64 ? 32 : 16), dpl = DP / lpp; };
+template <int DP> struct anom_layout16 { static constexpr int lpp = 16, dpl = DP / 16; };
+
+template <bool VOL>
+static __device__ __forceinline__ AggFrame agg_frame(const AggArgs& a, int frame)
+{
+    AggFrame fr;
+    fr.img = a.img + (size_t)frame * a.W * a.H;
+    fr.census_l = a.census_l + (size_t)frame * a.W * a.H;
+    fr.census_r = a.census_r + (size_t)frame * a.W * a.H;
+    fr.cost = VOL ? a.cost + (size_t)frame * a.W * a.H * a.Dp : nullptr;
+    fr.planes = a.planes + (size_t)frame * 8 * a.plane_bytes;
+    fr.extras = a.extras + (size_t)frame * 4 * a.H * a.Dp;
+    return fr;
+}
+
+// The four anomalous lines of every frame of the launch: one wave each (block = frame + B * (direction - 4)).  Its own kernel so
+// that its deep prefetch ring does not set the register count -- the occupancy -- of the regular lines' kernel, and its own launch
+// so that the host can run it BESIDE that kernel on a second stream (sgm_host.c launch_aggregation): inside the big launch these
+// four waves, one dependent memory round trip per step, were the last to finish (single frame: 0.34 ms against 0.21 for the
+// horizontal chains).  Lane layout of its own, whatever the regular lines of the batch use (extras rows and planes are plain [Dp]
+// cells): with non-negative P1 the whole wave works on the one line -- up to 64 lanes per pixel, the shortest step, as on the
+// horizontal lines of a single frame --; negative P1 and the volume-fed variant keep the generic step on 16 lanes.
+template <int DPL, bool PAD, int LPP, int NN, bool VOL>
+__global__ __launch_bounds__(64) void sgm_aggregate_anom_k(const AggArgs a)
+{
+    __shared__ unsigned short lut_s[256];
+    __shared__ unsigned lut32_s[256];
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned pen = a.lut[lane * 4 + i];
+        lut_s[lane * 4 + i] = (unsigned short)pen;
+        lut32_s[lane * 4 + i] = pen * 0x00010001u;
+    }
+    __syncthreads();
+    const AggFrame fr = agg_frame<VOL>(a, blockIdx.x % a.B);
+    agg_anomalous<DPL, PAD, LPP, NN, VOL>(a, fr, lut_s, lut32_s, 4 + blockIdx.x / a.B);
+}
 // NN: 0 = the generic step (any penalties; serves negative P1, for which the host keeps to 16 lanes per pixel everywhere,
 // sgm_host.c, so only those combinations are instantiated), 1 = the step for non-negative P1 (agg_step_nn), 2 = the same with the
 // FAST shortcuts for ordinary penalties (sgm_aggregate_fast.hip)
@@ -698,7 +818,7 @@ __global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
 
     // Batch: consecutive blocks are the same line group of consecutive frames, so every frame's long
     // horizontal lines are dispatched first.  Per frame, blocks [block_begin[d], block_begin[d+1]) are the
-    // regular lines of direction d; the last blocks (one per diagonal direction) are the anomalous lines.
+    // regular lines of direction d (the four anomalous diagonal lines run in a kernel of their own, sgm_aggregate_anom_k).
     //
     // Workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its own.  With 8 frames per launch frame f's blocks all
     // land on XCD f and its census images stay in that L2.  With fewer frames (the large shapes run 2 per launch, a single frame 1)
@@ -706,16 +826,20 @@ __global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
     // 8 / B XCDs, and every one of those L2s fetches the same rows (2880x1988 D=256: 5.3 GB of census reads per frame against
     // 46 MB of census data).  a.strips = 8 / B > 1: the frame keeps its 8 / B XCDs, and each of them takes one CONTIGUOUS strip of
     // every direction's line groups, in the order horizontal lines first.
+    // The four anomalous lines of a frame (a.anom_inline) come FIRST in both numberings: one wave each, H - 1 steps -- started
+    // behind everything else they would be the tail of the launch.  b >= block_begin[8] marks them below.
     int frame, b;
+    const int n_anom = a.anom_inline ? 4 : 0;
     if (a.strips > 1) {
         const int xcd = blockIdx.x & 7;
         frame = xcd % a.B;
         const int sub = xcd / a.B;
         int q = blockIdx.x >> 3;
         b = -1;
-        for (int d = 0; d <= 8; ++d) {                                     // 8 = the anomalous lines
+        for (int dd = 0; dd <= 8; ++dd) {
+            const int d = dd == 0 ? 8 : dd - 1;                            // 8 = the anomalous lines
             const int begin = a.block_begin[d];
-            const int n = (d < 8 ? a.block_begin[d + 1] : begin + (a.run_anom ? 4 : 0)) - begin;
+            const int n = (d < 8 ? a.block_begin[d + 1] : begin + n_anom) - begin;
             const int lo = sub * n / a.strips, share = (sub + 1) * n / a.strips - lo;
             if (q < share) { b = begin + lo + q; break; }
             q -= share;
@@ -724,17 +848,17 @@ __global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
     } else {
         frame = blockIdx.x % a.B;
         b = blockIdx.x / a.B;
+        b = b < n_anom ? a.block_begin[8] + b : b - n_anom;
     }
-    AggFrame fr;
-    fr.img = a.img + (size_t)frame * a.W * a.H;
-    fr.census_l = a.census_l + (size_t)frame * a.W * a.H;
-    fr.census_r = a.census_r + (size_t)frame * a.W * a.H;
-    fr.cost = VOL ? a.cost + (size_t)frame * a.W * a.H * a.Dp : nullptr;
-    fr.planes = a.planes + (size_t)frame * 8 * a.plane_bytes;
-    fr.extras = a.extras + (size_t)frame * 4 * a.H * a.Dp;
-    if (b >= a.block_begin[8]) {
-        agg_anomalous<DPL, PAD, LPP, VOL>(a, fr, lut_s, 4 + (b - a.block_begin[8]));
-        return;
+    const AggFrame fr = agg_frame<VOL>(a, frame);
+    if constexpr (NN != 0 && !VOL) {
+        // lane layout of its own (anom_layout: the whole wave on the one line where the cell is wide enough): fewer registers
+        // than the regular lines need, so the branch does not cost them occupancy
+        if (b >= a.block_begin[8]) {
+            using AL = anom_layout<DPL * LPP>;
+            agg_anomalous<AL::dpl, PAD, AL::lpp, 1, false>(a, fr, lut_s, lut32_s, 4 + (b - a.block_begin[8]));
+            return;
+        }
     }
     int dir = 0;
     while (dir + 1 < a.ndirs && b >= a.block_begin[dir + 1]) ++dir;
