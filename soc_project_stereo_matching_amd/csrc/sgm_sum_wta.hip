@@ -579,6 +579,7 @@ int sgmd_sum_wta_lr(int ord, void* stream, const sgmd_geom* g, int ndirs, const 
     // shorter than 2 Dp columns (each re-sums dmin + D - 1 columns of its right neighbour), and one segment whenever S
     // is read or written (the overlap would be accumulated twice)
     const int rows = (g->row_end - g->row_begin) * g->B;
+    static const int tight = getenv("SGM_SUM_TIGHT") ? atoi(getenv("SGM_SUM_TIGHT")) : 1;   // Dp 192 / 256: see TIGHT above
     int segs = 1;
     if (!accumulate && !store_S) {
         const char* e = getenv("SGM_SUM_SEGMENTS");
@@ -586,8 +587,20 @@ int sgmd_sum_wta_lr(int ord, void* stream, const sgmd_geom* g, int ndirs, const 
         if (segs > 4) segs = 4;
         while (segs > 1 && g->W / segs < 2 * g->Dp) --segs;
         if (segs < 1) segs = 1;
+        if (!(e && *e)) {
+            // ... and where some segment count lets ALL workgroups of the launch be resident at once, the largest such count: a
+            // second, partly filled round of workgroups costs more than the longer segments (KITTI, one frame: 375 rows x 3
+            // segments = 1125 workgroups on 768 slots took 0.123 ms, x 2 = 750 workgroups 0.103 ms).  Slots: 256 CUs x what the
+            // ring (LDS) and the wave count of a workgroup allow.
+            const int threads = g->Dp == 192 ? (tight ? 1024 : 512) : g->Dp == 256 ? (tight ? 512 : 256) : 256;
+            const int ring_cols = g->Dp + (((g->Dp == 192 || g->Dp == 256) && tight) ? 1 : 2) * (threads / 16) + g->Dp / 16;
+            const size_t lds = (size_t)ring_cols * (size_t)(g->Dp + 2) * 2 + SUMLR_MAX_EXTRA * (size_t)g->Dp + 64;
+            const size_t by_lds = ((size_t)160 << 10) / lds, by_waves = 32 / (size_t)(threads / 64);
+            const long slots = 256L * (long)(by_lds < by_waves ? by_lds : by_waves);
+            for (int sg = 4; sg >= 1; --sg)
+                if ((long)rows * sg <= slots && (sg == 1 || g->W / sg >= 2 * g->Dp)) { segs = sg; break; }
+        }
     }
-    static const int tight = getenv("SGM_SUM_TIGHT") ? atoi(getenv("SGM_SUM_TIGHT")) : 1;   // Dp 192 / 256: see TIGHT above
     const int seg_len = (((g->W + segs - 1) / segs) + 15) / 16 * 16;
     const dim3 grid(g->row_end - g->row_begin, g->B, (g->W + seg_len - 1) / seg_len);
     hipStream_t st = (hipStream_t)stream;
