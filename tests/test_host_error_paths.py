@@ -189,9 +189,10 @@ def test_async_match_hands_over_at_wait(host):
 
 
 def test_staged_result_is_handed_over_in_pieces(host):
-    """A result of 256 KiB or more that has to be staged (pageable caller buffer) comes back in four pieces with an event behind
-    each of the first three; sgm_match_wait copies piece i to the caller while piece i + 1 is still on the bus, and the caller
-    ends up with exactly the staged bytes."""
+    """A result of 256 KiB or more that has to be staged (pageable caller buffer) comes back in pieces -- two below 4 MiB, four above
+    (that size does not fit the stub's capped allocations: the GPU tests of batches through pageable buffers run it) -- with an
+    event behind each but the last; sgm_match_wait copies piece i to the caller while piece i + 1 is still on the bus, and the
+    caller ends up with exactly the staged bytes."""
     L = host
     L.sgm_match_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.sgm_match_wait.argtypes = [C.c_void_p]
@@ -204,14 +205,14 @@ def test_staged_result_is_handed_over_in_pieces(host):
     assert L.sgm_match_async(s, img.ctypes.data, img.ctypes.data, out.ctypes.data)
     names = [L.stub_log_name(i).decode() for i in range(L.stub_log_size())]
     tail = names[names.index("median") + 1:]
-    assert tail == ["d2h", "event_record", "d2h", "event_record", "d2h", "event_record", "d2h"]
+    assert tail == ["d2h", "event_record", "d2h"]
     sizes = [L.stub_log_arg(i) for i in range(L.stub_log_size()) if L.stub_log_name(i) == b"d2h"]
     assert sum(sizes) == w * h * 4 and all(n % 4 == 0 for n in sizes)
     assert names.index("h2d") < names.index("census")
     L.stub_clear()
     assert L.sgm_match_wait(s)
     names = [L.stub_log_name(i).decode() for i in range(L.stub_log_size())]
-    assert names.count("event_sync") == 3 and names[-1] == "sync"
+    assert names.count("event_sync") == 1 and names[-1] == "sync"
     assert not np.any(out == -1.0)                                   # every piece reached the caller (the stub's device memory is zeroed)
     L.sgm_destroy(s)
 
