@@ -71,3 +71,27 @@ def test_defaults_are_the_driver_contract():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert '"--gpus", type=int, default=1' in src and '"--steps"' in src and '"--warmup"' in src
     assert bench.HBM_PEAK_GBS == 8000.0 and bench.PATHS == 8
+
+
+def test_committed_bench_line_has_the_contract_keys():
+    """profiles/r03_bench.json is a line the driver's command printed on an MI355X for the committed kernels: the keys the contract
+    names, both extra objects, every single-GPU BASELINE workload verified, nothing mismatched."""
+    with open(os.path.join(ROOT, "profiles", "r03_bench.json")) as f:
+        d = json.load(f)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["source_id"] == bench.source_id() and d["n_gpus"] == 1 and d["config"]["workload"] == "kitti_1242x375_d128_p8"
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "valu") and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] and not r["traffic_stale"]
+    assert d["cpu_baseline"]["kind"] == "reference" and d["cpu_baseline"]["cores"] == 1
+    assert d["frames_mismatched"] == 0 and d["frames_verified"] >= 32
+    names = {w["workload"]: w for w in d["workloads"]}
+    for wl in ("cone_450x375_d64_p8", "cone_450x375_d64_p4", "middlebury_2880x1988_d256_p8", "drivingstereo_1762x800_d192_p8",
+               "kitti_1242x375_d128_p8_nospeckle"):
+        assert names[wl]["frames_mismatched"] == 0 and names[wl]["frames_verified"] > 0 and names[wl]["roofline"], wl
+    assert d["stream"]["frames"] >= 256 and d["stream"]["frames_mismatched"] == 0
+    hb = d["host_boundary"]
+    assert all(hb[k]["verified"] for k in ("blocking_single_frame", "blocking_single_frame_pinned", "pipelined_pageable"))
+
