@@ -228,6 +228,115 @@ def kernel_roofline(kernel, ms, launches, min_ms, B, counters, alg_bytes_per_fra
     return r
 
 
+COMPACT_LIMIT = 4096           # the driver keeps ~8 KB of stdout: the LAST line must be one short JSON object
+
+
+def _rf_compact(rf):
+    """The roofline object the contract names (bound / achieved / peak / unit / frac / traffic) plus what the judge recomputes it from."""
+    if not rf:
+        return None
+    out = {k: rf.get(k) for k in ("kernel", "bound", "frac", "achieved", "peak", "unit", "traffic", "algorithmic_bytes_per_launch",
+                                   "avg_launch_ms", "launches_timed", "frames_per_launch")}
+    out["algorithmic_frac"] = rf.get("algorithmic_frac")
+    out["traffic_stale"] = rf.get("traffic_stale")
+    out["valu_frac"] = (rf.get("valu") or {}).get("frac")
+    al = rf.get("alone") or {}
+    out["alone_frac"] = al.get("frac", al.get("algorithmic_frac"))
+    out["alone_launch_ms"] = al.get("avg_launch_ms")
+    out["alone_valu_frac"] = al.get("valu_frac")
+    return out
+
+
+def _frac_of(rf, alone=False):
+    if not rf:
+        return None
+    if alone:
+        al = rf.get("alone") or {}
+        return al.get("frac", al.get("algorithmic_frac"))
+    return rf.get("frac")
+
+
+def compact_line(line, detail="bench_detail.json"):
+    """The ONE short JSON line rank 0 prints LAST (< COMPACT_LIMIT bytes): the contract keys, `roofline` + `cpu_baseline`, and a
+    one-row summary of every other leg.  Everything else lives in the detail file / the earlier stdout line."""
+    cfg = line.get("config") or {}
+    entry = cfg.get("entry") or ""
+    out = {k: line.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data")}
+    out["metric"] = "Mdisp/s (W*H*D*paths/s; t_frame incl. H2D + D2H)"
+    out["dtype"] = "u8"
+    out["config"] = {k: cfg.get(k) for k in ("workload", "mode", "width", "height", "disparity_range", "paths", "frames_per_step",
+                                             "frames_per_launch", "instances_per_gpu") if k in cfg}
+    out["config"]["entry"] = entry.split(":")[0][:80]
+    for k in ("fps", "ms_per_frame", "frames_verified", "frames_mismatched", "verified_against_golden", "source_id"):
+        if k in line:
+            out[k] = line[k]
+    out["roofline"] = _rf_compact(line.get("roofline"))
+    if line.get("roofline_sum_wta"):
+        out["roofline_sum_wta"] = _rf_compact(line["roofline_sum_wta"])
+    ft = line.get("frame_traffic")
+    if ft:
+        out["frame_traffic"] = {"hbm_bytes_per_frame": ft.get("hbm_bytes_per_frame"), "frac_of_peak": ft.get("frac_of_peak"), "stale": ft.get("stale")}
+    cb = line.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "fps", "host_cpu", "host_cores")}
+        out["cpu_baseline"]["sample"] = (cb.get("sample") or "")[:100]
+        c16 = cb.get("cores_16") or {}
+        if "fps" in c16:
+            out["cpu_baseline"]["fps_16_cores"] = c16["fps"]
+        out["speedup_vs_cpu_baseline"] = line.get("speedup_vs_cpu_baseline")
+    else:
+        out["cpu_baseline"] = None
+    if line.get("sustained"):
+        out["sustained_fps"] = line["sustained"].get("fps")
+    dev = line.get("device_resident")
+    if dev:
+        out["device_resident"] = {"fps": dev.get("fps"), "verified": dev.get("frames_verified"), "mismatched": dev.get("frames_mismatched"),
+                                  "fps_all_ranks": dev.get("fps_all_ranks")}
+    if "single_frame_latency_ms" in line:
+        out["single_frame_latency_ms"] = line["single_frame_latency_ms"]
+    hb = line.get("host_boundary")
+    if hb:
+        out["host_boundary"] = {k: v.get("fps") for k, v in hb.items()}
+    if line.get("workloads"):
+        out["workloads_columns"] = ["fps", "verified", "mismatched", "agg_frac", "sum_frac", "agg_alone_frac", "sum_alone_frac"]
+        out["workloads"] = {}
+        for wl in line["workloads"]:
+            if "error" in wl:
+                out["workloads"][wl["workload"]] = "error"
+                continue
+            out["workloads"][wl["workload"]] = [wl.get("fps"), wl.get("frames_verified"), wl.get("frames_mismatched"),
+                                                _frac_of(wl.get("roofline")), _frac_of(wl.get("roofline_sum_wta")),
+                                                _frac_of(wl.get("roofline"), True), _frac_of(wl.get("roofline_sum_wta"), True)]
+    st = line.get("stream")
+    if st:
+        out["stream"] = {k: st.get(k) for k in ("workload", "frames", "fps", "frames_verified", "frames_mismatched")} if "error" not in st else "error"
+    out["detail"] = detail
+    s = json.dumps(out)
+    if len(s) >= COMPACT_LIMIT:                     # never let an extra leg break the contract line: drop summaries, keep the contract
+        for k in ("workloads_columns", "workloads", "stream", "host_boundary", "frame_traffic", "roofline_sum_wta"):
+            out.pop(k, None)
+            if len(json.dumps(out)) < COMPACT_LIMIT:
+                break
+    return out
+
+
+def emit(line):
+    """Rank 0's output.  stdout carries exactly ONE line -- the compact contract line (the driver keeps only the tail of stdout; a
+    21 KB line was cut in round 3) --; the full object goes to bench_detail.json (best effort: beside the script and under
+    gpurun_out/) and to stderr."""
+    full = json.dumps(line)
+    for path in (os.path.join(ROOT, "bench_detail.json"), os.path.join(ROOT, "gpurun_out", "bench_detail.json")):
+        try:
+            if os.path.isdir(os.path.dirname(path)):
+                with open(path, "w") as f:
+                    f.write(full + "\n")
+        except OSError:
+            pass
+    print(full, file=sys.stderr, flush=True)
+    print(json.dumps(compact_line(line)), flush=True)
+
+
 def init_dist(args):
     import torch
     import torch.distributed as dist
@@ -900,16 +1009,16 @@ def run_frames(args):
             if "cpu" in legs and not args.no_cpu_baseline:
                 cb = cpu_baseline(w, h, d, seed)
                 try:
-                    cb["all_cores"] = cpu_baseline_all_cores(w, h, d, seed)
+                    cb["cores_16"] = cpu_baseline_all_cores(w, h, d, seed)
                 except Exception as e:                                   # the one-core figure is the contract; this one is extra
-                    cb["all_cores"] = {"error": repr(e)}
+                    cb["cores_16"] = {"error": repr(e)}
                 line["cpu_baseline"] = cb
                 line["speedup_vs_cpu_baseline"] = round(value / cb["value"], 1)
             else:
                 line["cpu_baseline"] = None
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line), flush=True)
+        emit(line)
 
     if world > 1:
         dist.destroy_process_group()
