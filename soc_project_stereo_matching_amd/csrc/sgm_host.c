@@ -1115,11 +1115,13 @@ bool sgm_match_wait(sgm_instance* s)
     if (!s->async_pending) return true;
     s->async_pending = false;
     size_t done = 0;
-    if (s->async_out && s->async_chunks > 1) {
+    const int chunks = s->async_chunks;
+    s->async_chunks = 1;                                         /* whatever happens below, the next match starts clean */
+    if (s->async_out && chunks > 1) {
         /* the pieces as they arrive; a map that turns out invalid (sgm_synchronize below) has been handed over in part, as a
          * failed SGM_Match leaves its output undefined */
-        const size_t piece = s->async_bytes / (size_t)s->async_chunks / 4 * 4;
-        for (int i = 0; i + 1 < s->async_chunks; ++i) {
+        const size_t piece = s->async_bytes / (size_t)chunks / 4 * 4;
+        for (int i = 0; i + 1 < chunks; ++i) {
             if (sgmd_event_sync(s->device, s->ev_chunk[i]) != 0) break;
             memcpy((char*)s->async_out + done, (const char*)s->h_disp + done, piece);
             done += piece;
@@ -1128,6 +1130,7 @@ bool sgm_match_wait(sgm_instance* s)
     if (!sgm_synchronize(s)) return false;
     if (s->async_out) memcpy((char*)s->async_out + done, (const char*)s->h_disp + done, s->async_bytes - done);   /* .c:122 */
     s->async_out = NULL;
+    s->async_chunks = 1;
     return true;
 }
 
@@ -1262,6 +1265,7 @@ bool sgm_match_planes_async(sgm_instance* s, const uint8_t* planes, float fx, fl
     s->async_pending = true;
     s->async_out = out_pinned ? NULL : depth;
     s->async_bytes = px * sizeof(float);
+    s->async_chunks = 1;                                         /* one copy: no chunk events of an earlier match to wait for */
     return true;
 }
 

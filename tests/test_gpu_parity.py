@@ -936,6 +936,45 @@ def test_match_planes_depth(oracle, batch, overlap, pinned):
         inst.close()
 
 
+@pytest.mark.parametrize("first", ["match", "match_async"])
+def test_match_planes_after_a_chunked_match_on_the_same_instance(oracle, first):
+    """A staged disparity map of >= 256 KB comes back in pieces, an event behind each (sgm_match_async); the platform-frame entry
+    queues ONE copy.  After such a match on the same instance sgm_match_planes must not walk the earlier match's chunk events
+    (they completed long ago: the caller would get most of the map before this match's copy has finished).  Pageable buffers,
+    a map of 410 KB, several rounds so a stale hand-over would show the previous frame's depth."""
+    import soc_project_stereo_matching_amd as S
+    from oracle.pyoracle import default_option
+    from oracle.platform_oracle import board_gray, disparity_to_depth
+    w, h, d = 640, 160, 32
+    assert w * h * 4 >= 256 << 10
+    fx, baseline, doffs = 1733.74, 536.62, 0.0
+    opt = S.default_option(d)
+    rng = np.random.default_rng(1262)
+    inst = S.SGMInstance(0)
+    try:
+        for rep in range(3):
+            l, r = oracle.synth_pair(w, h, d, 0xC400 + rep)
+            assert inst.reset(w, h, opt)
+            if first == "match":
+                out = inst.match(l, r)
+                assert out is not None
+            else:
+                out = np.empty((h, w), np.float32)
+                assert inst.match_async(l, r, out) and inst.match_wait()
+            assert_same(out, oracle.run(l, r, default_option(d))["final"], f"chunked match {rep}")
+            planes = _colour_planes(oracle, w, h, d, 0xC500 + rep, rng)
+            depth = np.full((h, w), -1.0, np.float32)
+            assert inst.reset(w, h, opt)
+            assert inst.match_planes(np.ascontiguousarray(planes), fx, baseline, doffs, depth)
+            gl, gr = board_gray(planes[0], planes[1], planes[2]), board_gray(planes[3], planes[4], planes[5])
+            want = disparity_to_depth(oracle.run(gl, gr, default_option(d))["final"], fx, baseline, doffs)
+            assert np.array_equal(np.isnan(depth), np.isnan(want)), rep
+            ok = ~np.isnan(want)
+            assert np.array_equal(depth[ok].view(np.uint32), want[ok].view(np.uint32)), rep
+    finally:
+        inst.close()
+
+
 @pytest.mark.parametrize("flags,setup", [
     (["--paths", "4"], dict(honor=True, num_paths=4)),
     (["--census", "7x7"], dict(window=(7, 7))),
