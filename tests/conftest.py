@@ -39,8 +39,12 @@ def oracle():
 
 @pytest.fixture(scope="session")
 def golden_cases():
-    with open(os.path.join(GOLDEN, "cases.json")) as f:
-        return {c["name"]: c for c in json.load(f)["cases"]}
+    cases = {}
+    # cases.json: make_golden.py; cases_scenes.json: make_golden_scenes.py (the reference's Cloth3 / Reindeer / Wood2 pairs)
+    for name in ("cases.json", "cases_scenes.json"):
+        with open(os.path.join(GOLDEN, name)) as f:
+            cases.update({c["name"]: c for c in json.load(f)["cases"]})
+    return cases
 
 
 def option_from_dict(d):
@@ -63,8 +67,10 @@ def case_inputs(case, oracle):
     if case["name"] == "cone":
         z = load_npz("cone_inputs.npz")
         return z["left"], z["right"]
-    if "file" in case:
-        z = load_npz(case["file"])
+    if "file" in case or "inputs_file" in case:
+        z = load_npz(case.get("file") or case["inputs_file"])
+        if "sha256_inputs" in case:
+            assert sha(z["left"]) == case["sha256_inputs"]["left"] and sha(z["right"]) == case["sha256_inputs"]["right"]
         return z["left"], z["right"]
     l, r = oracle.synth_pair(case["w"], case["h"], case["d"], case["seed"])
     assert sha(l) == case["sha256_inputs"]["left"] and sha(r) == case["sha256_inputs"]["right"]

@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 GOLDEN_CASES = ["cone", "t24x16_d8", "t70x33_d16", "t20x31_d8_tall", "t40x24_d16_dmin3", "t33x33_d12_square",
                 "t64x20_d40", "v_default", "v_no_unique", "v_no_lr", "v_no_speckle", "v_plain", "v_p1_0_p2_0",
                 "v_p2_small", "v_p_big", "v_ratio_095", "v_lr_thres_0", "v_speckle_area_400", "v_num_paths_4_ignored",
-                "c1_synth_450x375_d64", "c2_kitti_1242x375_d128", "d256_400x48", "d192_300x60"]
+                "c1_synth_450x375_d64", "c2_kitti_1242x375_d128", "d256_400x48", "d192_300x60",
+                # real scenes: the pairs the reference ships beside cone (Data/Cloth3, Reindeer, Wood2; make_golden_scenes.py)
+                "scene_cloth3", "scene_reindeer", "scene_wood2"]
 
 
 def bits(a):
@@ -449,6 +451,34 @@ def test_c_driver_reproduces_the_reference_fixture(tmp_path):
     assert np.argwhere(got != z["im2_d_png"]).tolist() == [[374, 153]]
     raw = np.fromfile(out_raw, np.float32).reshape(375, 450)
     assert_same(raw, load_npz("cone_final.npz")["final"], "driver raw disparities")
+
+
+def test_c_driver_on_a_colour_scene(tmp_path):
+    """sgm_main on the RGB files of a second scene (Data/Reindeer view1 / view5, 671x555, stored as arrays by
+    make_golden_scenes.py and written back as an RGB PNG and an RGB PPM here): the driver's own colour -> grey conversion
+    (stb's formula, main.c's loader) must give the grey images the reference's loader gave, and the raw disparities the
+    final map of the compiled reference for that pair (max_disparity 128 from drange.txt)."""
+    import json
+    import os
+    import subprocess
+    from PIL import Image
+    from conftest import GOLDEN, ROOT
+    exe = os.path.join(ROOT, "soc_project_stereo_matching_amd", "sgm_main")
+    z = load_npz("scene_reindeer.npz")
+    with open(os.path.join(GOLDEN, "cases_scenes.json")) as f:
+        case = {c["name"]: c for c in json.load(f)["cases"]}["scene_reindeer"]
+    h, w = z["left"].shape
+    Image.fromarray(z["rgb_left"], "RGB").save(str(tmp_path / "view1.png"))
+    Image.fromarray(z["rgb_right"], "RGB").save(str(tmp_path / "view5.ppm"))
+    for src, want in (("view1.png", z["left"]), ("view5.ppm", z["right"])):       # the readers alone (--convert)
+        subprocess.check_call([exe, "--convert", str(tmp_path / src), str(tmp_path / "g.pgm")])
+        assert np.array_equal(np.asarray(Image.open(str(tmp_path / "g.pgm"))), want), src
+    out_png, out_raw = str(tmp_path / "d.png"), str(tmp_path / "d.f32")
+    subprocess.check_call([exe, str(tmp_path / "view1.png"), str(tmp_path / "view5.ppm"), out_png, "--max-disparity", "128", "--raw", out_raw])
+    raw = np.fromfile(out_raw, np.float32).reshape(h, w)
+    assert sha(raw) == case["sha256"]["final"]
+    assert_same(raw, z["final"], "driver raw disparities, Reindeer")
+    assert int(np.isinf(raw).sum()) == case["invalid_final"]
 
 
 def _bench_frames(workload):
