@@ -63,6 +63,12 @@ typedef struct {
 bool sgm_tile_rows(int height, int world, int rank, int* r0, int* r1);
 /* a frame occupies its slot from tile_begin (step f) to the post pass (step f + lead + world + 1; one rank: f + lead) */
 int  sgm_tile_slots_needed(int world, int lead);
+/* Device memory one slot of a rank that owns rows [row_begin, row_end) takes: per frame of its batch the 8 direction planes of the tile's rows + one hand-over row
+ * either side (1 B per cell of the padded disparity range), ~64 B per pixel of the WHOLE frame (maps, census, labels, median
+ * scratch, the row-gather buffer) and 4 hand-over buffers.  A rank holds sgm_tile_slots_needed(world, lead) [+ spare - 1] of them:
+ * sgm_tiles_create and tiling.DeviceSlotEngine refuse a configuration that does not fit (DESIGN.md section 7 has the table).
+ * 0 for an empty or out-of-frame row range. */
+size_t sgm_tile_slot_bytes(int row_begin, int row_end, uint16_t width, uint16_t height, const SGMOption* option, int batch);
 /* steps a stream of n_frames takes until its last result is queued */
 long sgm_tile_steps_total(long n_frames, int world, int lead);
 /* Step `step` (0, 1, 2, ...) of rank `rank`, `frames_known` = how many frames exist so far (a frame may be begun in the step

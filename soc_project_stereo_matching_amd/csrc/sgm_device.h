@@ -41,6 +41,9 @@ int   sgmd_host_is_pinned(int ordinal, const void* hptr, size_t bytes);   /* 1: 
 int   sgmd_h2d_async(int ordinal, void* stream, void* dst, const void* src, size_t bytes);
 int   sgmd_d2h_async(int ordinal, void* stream, void* dst, const void* src, size_t bytes);
 int   sgmd_d2d_async(int ordinal, void* stream, void* dst, const void* src, size_t bytes);
+/* `rows` pieces of `width` bytes each, `src_pitch` / `dst_pitch` bytes apart (device to device; the row gather of a batch packs the same
+ * rows of every map into one message this way) */
+int   sgmd_d2d_2d_async(int ordinal, void* stream, void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width, size_t rows);
 /* One image row of up to 8 direction planes of every frame of the batch <-> a packed buffer [frame][k][row_bytes] (the row-tile
  * hand-over): plane d = dirs[k] of frame f starts at planes + (f * 8 + d) * plane_bytes; to_buf != 0 gathers, else scatters. */
 int   sgmd_plane_rows_copy(int ordinal, void* stream, void* planes, size_t plane_bytes, size_t row_offset, size_t row_bytes,

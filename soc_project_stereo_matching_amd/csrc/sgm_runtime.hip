@@ -214,6 +214,12 @@ int sgmd_d2d_async(int ord, void* stream, void* dst, const void* src, size_t byt
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return 0;
 }
+int sgmd_d2d_2d_async(int ord, void* stream, void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width, size_t rows)
+{
+    HIP_TRY(hipSetDevice(ord));
+    HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width, rows, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
 int sgmd_memset_async(int ord, void* stream, void* dst, int value, size_t bytes)
 {
     HIP_TRY(hipSetDevice(ord));

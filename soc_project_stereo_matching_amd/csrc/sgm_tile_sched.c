@@ -20,6 +20,15 @@ bool sgm_tile_rows(int height, int world, int rank, int* r0, int* r1)
     return true;
 }
 
+size_t sgm_tile_slot_bytes(int r0, int r1, uint16_t width, uint16_t height, const SGMOption* option, int batch)
+{
+    if (!option || batch < 1 || r0 < 0 || r1 <= r0 || r1 > height) return 0;
+    const int D = (uint16_t)(option->max_disparity - option->min_disparity);
+    const size_t Dp = D <= 32 ? 32 : D <= 64 ? 64 : D <= 128 ? 128 : D <= 192 ? 192 : D <= 256 ? 256 : 512;   /* sgm_host.c's padded range */
+    const size_t rows = (size_t)(r1 - r0) + (r1 - r0 < height ? 2 : 0);
+    return (size_t)batch * (8 * rows * width * Dp + (size_t)64 * width * height + 4 * 3 * (size_t)width * Dp);
+}
+
 int sgm_tile_slots_needed(int world, int lead) { return (world > 1 ? world + 3 : 2) + lead; }
 
 long sgm_tile_steps_total(long n_frames, int world, int lead) { return n_frames + world + 2 + lead; }

@@ -35,6 +35,7 @@ typedef struct {
     sgm_instance* inst;
     void* stream;                 /* = sgm_stream(inst) */
     void* d_map;                  /* [batch][H][W] float32 */
+    void* d_pack;                 /* batches on several ranks: the row gather's message buffer, [rank k: [batch][rows of k][W]] at batch * r0(k) * W */
     void* bnd[2][2];              /* [forward][incoming] hand-over buffers */
     void* ev_done;                /* re-recorded behind the slot's last queued work */
 } tile_slot;
@@ -115,7 +116,7 @@ static int eng_exchange(void* u, const sgm_tile_xop* ops, int n_ops, const int* 
         if (sgmd_event_record(dev, s->ev_done, s->stream) != 0 || sgmd_stream_wait_event(dev, t->comm_stream, s->ev_done) != 0) return -12;
     }
     if (t->tr.group_start(t->tr.ctx) != 0) return -13;
-    int rc = 0;
+    int rc = 0, unpack[64], n_unpack = 0;
     for (int i = 0; i < n_ops && rc == 0; ++i) {
         const sgm_tile_xop* o = &ops[i];
         tile_slot* s = &t->slots[o->slot];
@@ -124,16 +125,38 @@ static int eng_exchange(void* u, const sgm_tile_xop* ops, int n_ops, const int* 
             rc = o->kind == SGM_XOP_SEND ? t->tr.send(t->tr.ctx, b, t->bnd_bytes, o->peer, t->comm_stream)
                                          : t->tr.recv(t->tr.ctx, b, t->bnd_bytes, o->peer, t->comm_stream);
         } else {
-            /* rows [row_begin, row_end) of every map of the slot: contiguous per frame of the batch */
-            const size_t bytes = (size_t)(o->row_end - o->row_begin) * t->W * sizeof(float);
-            for (int b = 0; b < t->batch && rc == 0; ++b) {
-                char* p = (char*)s->d_map + ((size_t)b * t->H + (size_t)o->row_begin) * t->W * sizeof(float);
-                rc = o->kind == SGM_XOP_SEND ? t->tr.send(t->tr.ctx, p, bytes, o->peer, t->comm_stream)
-                                             : t->tr.recv(t->tr.ctx, p, bytes, o->peer, t->comm_stream);
+            /* rows [row_begin, row_end) of every map of the slot.  One frame per step: they are contiguous in the map.  A batch: the
+             * same rows of its B maps travel as ONE message per peer -- packed into / unpacked from the slot's d_pack by one strided
+             * device copy on the communication stream (per step world - 1 messages on the owner instead of (world - 1) * B; the
+             * exchange is latency-bound) */
+            const size_t rows = (size_t)(o->row_end - o->row_begin), row_bytes = (size_t)t->W * sizeof(float);
+            char* const in_map = (char*)s->d_map + (size_t)o->row_begin * row_bytes;
+            if (t->batch == 1) {
+                rc = o->kind == SGM_XOP_SEND ? t->tr.send(t->tr.ctx, in_map, rows * row_bytes, o->peer, t->comm_stream)
+                                             : t->tr.recv(t->tr.ctx, in_map, rows * row_bytes, o->peer, t->comm_stream);
+            } else {
+                char* const packed = (char*)s->d_pack + (size_t)t->batch * (size_t)o->row_begin * row_bytes;
+                if (o->kind == SGM_XOP_SEND) {
+                    rc = sgmd_d2d_2d_async(dev, t->comm_stream, packed, rows * row_bytes, in_map, (size_t)t->H * row_bytes, rows * row_bytes,
+                                           (size_t)t->batch) != 0
+                             ? -1 : t->tr.send(t->tr.ctx, packed, (size_t)t->batch * rows * row_bytes, o->peer, t->comm_stream);
+                } else {
+                    rc = t->tr.recv(t->tr.ctx, packed, (size_t)t->batch * rows * row_bytes, o->peer, t->comm_stream);
+                    if (n_unpack < 64) unpack[n_unpack++] = i;
+                    else rc = -1;
+                }
             }
         }
     }
     if (t->tr.group_end(t->tr.ctx) != 0 || rc != 0) return -14;
+    for (int k = 0; k < n_unpack; ++k) {                             /* behind the group: the received rows into their maps */
+        const sgm_tile_xop* o = &ops[unpack[k]];
+        tile_slot* s = &t->slots[o->slot];
+        const size_t rows = (size_t)(o->row_end - o->row_begin), row_bytes = (size_t)t->W * sizeof(float);
+        if (sgmd_d2d_2d_async(dev, t->comm_stream, (char*)s->d_map + (size_t)o->row_begin * row_bytes, (size_t)t->H * row_bytes,
+                              (char*)s->d_pack + (size_t)t->batch * (size_t)o->row_begin * row_bytes, rows * row_bytes, rows * row_bytes,
+                              (size_t)t->batch) != 0) return -17;
+    }
     /* ... and afterwards those slots' streams wait for the exchange */
     if (sgmd_event_record(dev, t->ev_comm, t->comm_stream) != 0) return -15;
     for (int i = 0; i < n_slots; ++i)
@@ -162,6 +185,7 @@ void sgm_tiles_destroy(sgm_tiles* t)
             tile_slot* s = &t->slots[i];
             sgmd_event_destroy(t->device, s->ev_done);
             sgmd_free(t->device, s->d_map);
+            sgmd_free(t->device, s->d_pack);
             for (int a = 0; a < 2; ++a)
                 for (int b = 0; b < 2; ++b) sgmd_free(t->device, s->bnd[a][b]);
             sgm_destroy(s->inst);
@@ -194,12 +218,8 @@ sgm_tiles* sgm_tiles_create(int device, int rank, int world, uint16_t width, uin
     }
     t->nslots = sgm_tile_slots_needed(world, lead) + spare - 1;
     {
-        /* what the slots will take: per frame of a batch 8 planes of the tile's rows + a hand-over row either side (1 B per cell
-         * of the padded range), ~60 B per pixel of the whole frame (maps, census, labels, median scratch), 4 hand-over buffers */
         const int D = (uint16_t)(option->max_disparity - option->min_disparity);
-        const size_t Dp = D <= 32 ? 32 : D <= 64 ? 64 : D <= 128 ? 128 : D <= 192 ? 192 : D <= 256 ? 256 : 512;
-        const size_t rows = (size_t)(t->r1 - t->r0) + 2;
-        const size_t per_slot = (size_t)batch * (8 * rows * width * Dp + (size_t)64 * width * height + 4 * 3 * (size_t)width * Dp);
+        const size_t per_slot = sgm_tile_slot_bytes(t->r0, t->r1, width, height, option, batch);
         size_t free_b = 0, total_b = 0;
         if (sgmd_mem_info(device, &free_b, &total_b) == 0 && per_slot * (size_t)t->nslots > free_b) {
             const size_t fit = free_b / (per_slot / (size_t)batch) / (size_t)t->nslots;
@@ -221,6 +241,7 @@ sgm_tiles* sgm_tiles_create(int device, int rank, int world, uint16_t width, uin
         ok = s->inst && sgm_set_batch(s->inst, batch) && sgm_set_rows(s->inst, t->r0, t->r1);
         if (ok) s->stream = sgm_stream(s->inst);
         ok = ok && sgmd_event_create(device, &s->ev_done) == 0 && sgmd_alloc(device, &s->d_map, map_bytes) == 0;
+        if (ok && world > 1 && batch > 1) ok = sgmd_alloc(device, &s->d_pack, map_bytes) == 0;
     }
     ok = ok && sgmd_stream_create(device, &t->comm_stream) == 0 && sgmd_event_create(device, &t->ev_comm) == 0;
     if (ok && throttle > 0) {
@@ -523,7 +544,11 @@ static int local_send(void* c, const void* buf, size_t bytes, int peer, void* st
 static int local_recv_post(void* c, void* buf, size_t bytes, int peer, void* stream)
 {
     local_ctx* x = (local_ctx*)c;
-    if (x->n_pending >= (int)(sizeof x->pending / sizeof x->pending[0]) || peer < 0 || peer >= x->g->world) return -1;
+    if (peer < 0 || peer >= x->g->world) return -1;
+    if (x->n_pending >= (int)(sizeof x->pending / sizeof x->pending[0])) {   /* sgm_tile_step lists at most 2 + (world - 1 <= 64) receives */
+        fprintf(stderr, "sgm_mi355x (tiles): more than %d receives in one group of the local transport\n", (int)(sizeof x->pending / sizeof x->pending[0]));
+        return -1;
+    }
     x->pending[x->n_pending++] = (local_recv){buf, bytes, peer, stream};
     return 0;
 }
@@ -551,6 +576,7 @@ static int local_group_end(void* c)
         if (rc == 0) rc = sgmd_stream_wait_event(g->device, r->stream, m->ev_sent);
         if (rc == 0) rc = sgmd_d2d_async(g->device, r->stream, r->buf, m->stage, r->bytes);
         if (rc == 0) rc = sgmd_event_record(g->device, m->ev_taken, r->stream);
+        if (rc != 0) m->used_before = false;                          /* no `taken` event behind this use: the next sender must not wait for one */
         pthread_mutex_lock(&g->mu);
         m->next = g->pool[r->peer];
         g->pool[r->peer] = m;

@@ -85,6 +85,8 @@ def _bind(L):
     L.sgm_tile_rows.restype = C.c_bool
     L.sgm_tile_slots_needed.argtypes = [i, i]
     L.sgm_tile_slots_needed.restype = i
+    L.sgm_tile_slot_bytes.argtypes = [i, i, C.c_uint16, C.c_uint16, p, i]
+    L.sgm_tile_slot_bytes.restype = C.c_size_t
     L.sgm_tile_steps_total.argtypes = [C.c_long, i, i]
     L.sgm_tile_steps_total.restype = C.c_long
     L.sgm_tile_step.argtypes = [C.POINTER(TileEngine), i, i, i, i, i, C.c_long, C.c_long]
@@ -119,6 +121,11 @@ def tile_rows(height: int, world: int, rank: int):
     if not lib().sgm_tile_rows(height, world, rank, C.byref(r0), C.byref(r1)):
         raise ValueError(f"cannot cut {height} rows into {world} tiles")
     return r0.value, r1.value
+
+
+def slot_bytes(row_begin: int, row_end: int, width: int, height: int, option, batch: int = 1) -> int:
+    """Device memory one slot of a rank owning rows [row_begin, row_end) takes (include/sgm_tiles.h: sgm_tile_slot_bytes)."""
+    return int(lib().sgm_tile_slot_bytes(row_begin, row_end, width, height, C.byref(option), batch))
 
 
 def slots_needed(world: int, lead: int = 0) -> int:

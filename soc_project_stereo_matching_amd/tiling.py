@@ -274,6 +274,14 @@ class DeviceSlotEngine(SlotEngine):
         self.w, self.h, self.rows, self.option, self.slots, self.batch = width, height, rows, option, slots, batch
         self.host_staged = host_staged              # gloo moves host tensors (rehearsals on a box whose ranks share one GPU)
         self.inst, self.stream, self.maps, self.bufs, self.keep = [], [], [], [], [None] * slots
+        # the same guard as sgm_tiles_create: say what does not fit (and what would) before hipMalloc fails half-way through
+        from . import tiles as _tiles
+        per_slot = _tiles.slot_bytes(rows[0], rows[1], width, height, option, batch)
+        free_b, _total = torch.cuda.mem_get_info(self.dev)
+        if per_slot and per_slot * slots > free_b:
+            fit = free_b // max(1, per_slot // batch) // slots
+            raise RuntimeError(f"{slots} slots x batch {batch} of {width}x{height} need about {per_slot * slots / 1e9:.1f} GB on device {device}, "
+                               f"{free_b / 1e9:.1f} GB are free: use a batch of at most {fit}, a smaller lead, or more ranks")
         for _ in range(slots):
             i = SGMInstance(device, batch=batch)         # batch > 1: a slot is a batch of frames ([B][H][W] images and maps)
             if not (i.set_rows(*rows) and i.reset(width, height, option)):

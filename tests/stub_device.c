@@ -84,6 +84,13 @@ int sgmd_plane_rows_copy(int o, void* st, void* planes, size_t pb, size_t ro, si
     return note(to_buf ? "rows_out" : "rows_in", nd * frames);
 }
 int sgmd_d2d_async(int o, void* st, void* d, const void* s, size_t n) { (void)o; (void)st; if (n <= (1u << 20)) memmove(d, s, n); return note("d2d", (int)n); }
+int sgmd_d2d_2d_async(int o, void* st, void* d, size_t dp, const void* s, size_t sp, size_t w, size_t rows)
+{
+    (void)o; (void)st;
+    if ((rows ? (rows - 1) * (dp > sp ? dp : sp) : 0) + w <= (1u << 20))
+        for (size_t r = 0; r < rows; ++r) memmove((char*)d + r * dp, (const char*)s + r * sp, w);
+    return note("d2d_2d", (int)(w * rows));
+}
 int sgmd_memset_async(int o, void* st, void* d, int v, size_t n) { (void)o; (void)st; if (n <= (1u << 20)) memset(d, v, n); return note("memset", (int)n); }
 
 int sgmd_timer_create(int o, void** t, int n) { (void)o; (void)n; *t = malloc(8); return 0; }

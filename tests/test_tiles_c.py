@@ -285,7 +285,8 @@ def check(got, lefts, batch):
             assert np.array_equal(m[b], want), (k, b, np.argwhere(m[b] != want)[:4])
 
 
-@pytest.mark.parametrize("world,batch,lead", [(1, 1, 0), (1, 2, 2), (2, 1, 0), (2, 2, 2), (3, 1, 2), (4, 2, 1), (4, 1, 3)])
+@pytest.mark.parametrize("world,batch,lead", [(1, 1, 0), (1, 2, 2), (2, 1, 0), (2, 2, 2), (3, 1, 2), (4, 2, 1), (4, 1, 3),
+                                              (8, 8, 2), (8, 1, 2)])       # the target node's shape: 8 ranks, 8 frames per step
 def test_pipeline_of_threads_over_the_local_transport(stub, world, batch, lead):
     L = stub
     from soc_project_stereo_matching_amd import tiles
@@ -307,7 +308,7 @@ def test_pipeline_of_threads_over_the_local_transport(stub, world, batch, lead):
         L.sgm_tiles_local_destroy(group)
 
 
-@pytest.mark.parametrize("world,batch,lead,throttle", [(2, 1, 2, 0), (3, 2, 1, 3), (4, 1, 2, 0)])
+@pytest.mark.parametrize("world,batch,lead,throttle", [(2, 1, 2, 0), (3, 2, 1, 3), (4, 1, 2, 0), (8, 8, 2, 0), (8, 1, 2, 3)])
 def test_pipeline_of_threads_over_rccl_bound_at_run_time(stub, world, batch, lead, throttle):
     """The RCCL transport of csrc/sgm_tiles.c (dlopen + ncclCommInitRank + grouped ncclSend / ncclRecv) against tests/stub_rccl.c,
     which completes a group's operations in another order than they were listed."""
@@ -329,9 +330,10 @@ def test_pipeline_of_threads_over_rccl_bound_at_run_time(stub, world, batch, lea
     check(got, lefts, batch)
     m1, b1 = C.c_ulonglong(), C.c_ulonglong()
     L.rccl_lib.stub_rccl_stats(C.byref(m1), C.byref(b1))
-    # per frame: 2 (N - 1) hand-overs of batch x 3 x W x Dp bytes and the rows of the other N - 1 ranks (one message per map of a batch)
+    # per frame: 2 (N - 1) hand-overs of batch x 3 x W x Dp bytes and the rows of the other N - 1 ranks -- ONE message per peer: the
+    # same rows of the B maps of a batch are packed (at 8 ranks x 8 frames the owner posts 7 row receives per step, not 56)
     bnd = batch * 3 * w * 32
-    want_msgs = n_steps * (2 * (world - 1) + (world - 1) * batch)
+    want_msgs = n_steps * (2 * (world - 1) + (world - 1))
     want_bytes = n_steps * (2 * (world - 1) * bnd + batch * sum(tiles.tile_rows(h, world, r)[1] - tiles.tile_rows(h, world, r)[0]
                                                                   for r in range(world)) * w * 4)
     own_rows = [tiles.tile_rows(h, world, r)[1] - tiles.tile_rows(h, world, r)[0] for r in range(world)]
@@ -383,6 +385,35 @@ def test_results_reach_their_owner_in_order_and_a_refused_launch_fails_the_submi
     assert not L.sgm_tiles_create(0, 0, 20, w, h, C.byref(opt), 1, 2, 1, 0, None)
     assert not L.sgm_tiles_create(0, 0, 2, w, h, C.byref(opt), 1, 2, 1, 0, None)
     assert not L.sgm_tiles_create(0, 3, 2, w, h, C.byref(opt), 1, 2, 1, 0, None)
+
+
+def test_slot_memory_estimate_and_the_guard_of_create(stub, capfd):
+    """sgm_tile_slot_bytes is what sgm_tiles_create and tiling.DeviceSlotEngine check against the free device memory.  The failed
+    round-3 rehearsal (2 ranks, 3840x2160 D=128, 8 frames per step) died in hipMalloc on 34 005 319 680 bytes of planes for ONE slot:
+    the estimate must contain exactly that; 7 slots of it do not fit a 288 GB GPU, and create says so with the batch that would."""
+    L = stub
+    import soc_project_stereo_matching_amd as S
+    from soc_project_stereo_matching_amd import tiles
+    opt = S.default_option(128)
+    w, h = 3840, 2160
+    r0, r1 = tiles.tile_rows(h, 2, 0)
+    per_slot = tiles.slot_bytes(r0, r1, w, h, opt, 8)
+    planes = 8 * 8 * (r1 - r0 + 1) * w * 128                          # rank 0: its rows + ONE hand-over row (an inner tile has two)
+    assert planes == 34005319680 and planes < per_slot < planes * 1.15             # + ~64 B per pixel of the frame
+    assert tiles.slot_bytes(0, h, w, h, opt, 1) == 8 * h * w * 128 + 64 * w * h + 12 * w * 128      # one rank: no hand-over rows
+    assert tiles.slot_bytes(5, 5, w, h, opt, 1) == 0 and tiles.slot_bytes(0, h + 1, w, h, opt, 1) == 0
+    # DESIGN.md section 7's table: GB per GPU for N = 1, 2, 4, 8 at a lead of 2
+    gb = {n: [tiles.slot_bytes(*tiles.tile_rows(h, n, 0), w, h, opt, b) * tiles.slots_needed(n, 2) / 1e9 for b in (1, 4, 8)] for n in (1, 2, 4, 8)}
+    assert [round(v) for v in gb[2]] == [34, 134, 268] and [round(v) for v in gb[8]] == [21, 84, 167]
+    # the stub device reports 200 GiB free: 2 ranks x batch 8 is refused with a message, batch 4 is accepted
+    group = L.sgm_tiles_local_group(2, 0)
+    tr = tiles.Transport()
+    assert L.sgm_tiles_local_transport(group, 0, C.byref(tr))
+    assert not L.sgm_tiles_create(0, 0, 2, w, h, C.byref(opt), 8, 2, 1, 0, C.byref(tr))
+    err = capfd.readouterr().err
+    assert "need about 268" in err and "batch of at most 6" in err
+    tr.close()
+    L.sgm_tiles_local_destroy(group)
 
 
 def test_first_use_from_several_threads_at_once():
