@@ -75,25 +75,47 @@ def match_sharded(frames: Sequence[Tuple[np.ndarray, np.ndarray]], matcher: Call
     `dist` is torch.distributed (already initialised) when world > 1.  Returns the full list on rank 0
     (or the rank's own results when gather_to_rank0 is False), None on the other ranks."""
     mine = frames_of_rank(len(frames), world, rank)
-    local = {i: matcher(frames[i][0], frames[i][1]) for i in mine}
+    local = {}
+    for i in mine:
+        m = matcher(frames[i][0], frames[i][1])
+        if m is None:                                             # a failed match must not travel as a map of zeros / NaNs
+            raise RuntimeError(f"matcher returned no result for frame {i} (rank {rank})")
+        local[i] = m
     if not gather_to_rank0:
         return [local[i] for i in mine]
     if world == 1:
         return [local[i] for i in range(len(frames))]
-    # one tensor gather of the ranks' maps (padded to the largest share): device buffers over RCCL when the matcher returns device
-    # tensors, host tensors over gloo in the CPU tests -- nothing is pickled through the host
+    # one tensor gather of the ranks' maps (padded to the largest share); nothing is pickled through the host.  The BACKEND decides
+    # where the gathered tensors live, the same on every rank whatever its matcher returned and however many frames it owns:
+    # RCCL ("nccl") moves device tensors only, so host maps (SGMStream returns numpy) are uploaded to the rank's GPU first; gloo
+    # moves host tensors, so device maps are downloaded.
     import torch
     most = -(-len(frames) // world)
     first = next(iter(local.values())) if local else None
     shape = [most] + list(first.shape if first is not None else np.shape(frames[0][0]))
-    on_device = (torch.is_tensor(first) and first.is_cuda) or (first is None and dist.get_backend() == "nccl")   # a rank without frames follows the backend
-    mine_t = torch.zeros(shape, dtype=torch.float32, device=(first.device if first is not None else "cuda") if on_device else "cpu")
+    on_device = dist.get_backend() == "nccl"
+    if on_device:
+        dev = first.device if (torch.is_tensor(first) and first.is_cuda) else torch.device("cuda", torch.cuda.current_device())
+    else:
+        dev = torch.device("cpu")
+    mine_t = torch.zeros(shape, dtype=torch.float32, device=dev)
     for k, i in enumerate(mine):
-        mine_t[k] = local[i] if torch.is_tensor(local[i]) else torch.from_numpy(np.ascontiguousarray(local[i], dtype=np.float32))
+        m = local[i] if torch.is_tensor(local[i]) else torch.from_numpy(np.ascontiguousarray(local[i], dtype=np.float32))
+        if tuple(m.shape) != tuple(shape[1:]):
+            raise RuntimeError(f"frame {i}: the matcher returned a map of shape {tuple(m.shape)}, expected {tuple(shape[1:])}")
+        mine_t[k] = m.to(dev)
+    # how many frames each rank really matched travels with the maps: rank 0 checks that no frame is missing
+    count = torch.tensor([len(local)], dtype=torch.int64, device=dev)
+    counts = [torch.empty_like(count) for _ in range(world)] if rank == 0 else None
+    dist.gather(count, counts, dst=0)
     parts = [torch.empty_like(mine_t) for _ in range(world)] if rank == 0 else None
     dist.gather(mine_t, parts, dst=0)
     if rank != 0:
         return None
+    for r in range(world):
+        want = len(frames_of_rank(len(frames), world, r))
+        if int(counts[r].item()) != want:
+            raise RuntimeError(f"rank {r} matched {int(counts[r].item())} of its {want} frames")
     out = []
     for i in range(len(frames)):
         m = parts[i % world][i // world]                     # frame i is the (i // world)-th frame of rank i % world

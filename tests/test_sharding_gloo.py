@@ -68,3 +68,77 @@ def test_two_ranks_gloo_equal_single_process(tmp_path, oracle):
         l, r = oracle.synth_pair(64, 24, 16, 0xF00D + k)
         want = oracle.run(l, r, opt)["final"]
         assert np.array_equal(got[f"arr_{k}"].view(np.uint32), want.view(np.uint32)), k
+
+
+class _FakeDist:
+    """Stands in for torch.distributed on ONE process: this rank is rank 0 of a world of 2; `other` makes what rank 1 would have
+    sent.  Checks what the real backends enforce: RCCL ("nccl") only moves device tensors, gloo only host tensors."""
+
+    def __init__(self, backend, other):
+        self.backend, self.other, self.seen = backend, other, []
+
+    def get_backend(self):
+        return self.backend
+
+    def gather(self, tensor, parts, dst=0):
+        assert tensor.is_cuda == (self.backend == "nccl"), f"{self.backend} cannot move a tensor on {tensor.device}"
+        self.seen.append(tuple(tensor.shape))
+        parts[0].copy_(tensor)
+        parts[1].copy_(self.other(tensor))
+
+
+def test_a_failed_match_is_an_error_not_a_map(oracle):
+    from soc_project_stereo_matching_amd.sharding import match_sharded
+    frames = [oracle.synth_pair(32, 12, 8, 0xF11D + k) for k in range(3)]
+    with pytest.raises(RuntimeError, match="no result for frame 1"):
+        match_sharded(frames, lambda l, r: None if l is frames[1][0] else np.zeros(l.shape, np.float32), 1, 0)
+
+
+def test_gather_checks_that_every_rank_matched_its_frames(oracle):
+    """Rank 0 of a world of 2 with a host matcher over a gloo-like backend: host tensors travel; a rank that reports fewer
+    matched frames than it owns is an error on rank 0."""
+    import torch
+    from soc_project_stereo_matching_amd.sharding import match_sharded
+    frames = [oracle.synth_pair(32, 12, 8, 0xF22D + k) for k in range(5)]
+    maps = [np.full((12, 32), float(k), np.float32) for k in range(5)]
+
+    def other(t):                                           # rank 1: its frame count, then frames 1 and 3 (padded to 3)
+        if t.dtype == torch.int64:
+            return torch.tensor([2], dtype=torch.int64)
+        return torch.from_numpy(np.stack([maps[1], maps[3], np.zeros((12, 32), np.float32)]))
+    fd = _FakeDist("gloo", other)
+    res = match_sharded(frames, lambda l, r: maps[[id(f[0]) for f in frames].index(id(l))], 2, 0, dist=fd)
+    assert [float(m[0, 0]) for m in res] == [0.0, 1.0, 2.0, 3.0, 4.0] and all(isinstance(m, np.ndarray) for m in res)
+
+    def short(t):
+        return torch.tensor([1], dtype=torch.int64) if t.dtype == torch.int64 else other(t)
+    with pytest.raises(RuntimeError, match="rank 1 matched 1 of its 2 frames"):
+        match_sharded(frames, lambda l, r: maps[0], 2, 0, dist=_FakeDist("gloo", short))
+
+
+@pytest.mark.gpu
+def test_host_maps_are_gathered_as_device_tensors_under_nccl():
+    """The product matcher (SGMStream) returns numpy maps; bench.py's process group is RCCL ("nccl"), which moves device tensors
+    only: match_sharded must upload the maps to the rank's GPU for the gather, whatever the matcher returned."""
+    import torch
+    import soc_project_stereo_matching_amd as S
+    from soc_project_stereo_matching_amd.sharding import SGMStream, match_sharded
+    w, h, d = 96, 40, 32
+    opt = S.default_option(d)
+    frames = [S.synth_pair(w, h, d, 0xF33D + k) for k in range(4)]
+    stream = SGMStream(0, w, h, opt, in_flight=2)
+    try:
+        want = [stream(l, r) for l, r in frames]
+
+        def other(t):
+            if t.dtype == torch.int64:
+                return torch.tensor([2], dtype=torch.int64, device=t.device)
+            return torch.from_numpy(np.stack([want[1], want[3]])).to(t.device)
+        fd = _FakeDist("nccl", other)
+        res = match_sharded(frames, stream, 2, 0, dist=fd)
+        assert fd.seen == [(1,), (2, h, w)]
+        assert all(torch.is_tensor(m) and m.is_cuda for m in res)
+        for k in range(4):
+            assert np.array_equal(res[k].cpu().numpy().view(np.uint32), want[k].view(np.uint32)), k
+    finally:
+        stream.close()
