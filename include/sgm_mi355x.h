@@ -152,14 +152,16 @@ bool          sgm_set_overlap_post(sgm_instance* s, int enable);
  * XCD keeps its L2 and its path to HBM in play); the groups are ordered by events, results are unchanged.
  *   count > 0   own stream on those CUs        count == 0  own stream, all CUs       count < 0  back to the default
  *   which = SGM_STAGE_MAIN: the stream census + aggregation (and every group without a stream of its own) run on; re-created,
- *   so sgm_stream(s) changes.   SGM_STAGE_POST with count == 0 is sgm_set_overlap_post(s, 1).
+ *   so sgm_stream(s) changes: a caller that cached the handle (the tile pipeline's slots do) must query it again, the old one
+ *   is destroyed.   SGM_STAGE_POST with count == 0 is sgm_set_overlap_post(s, 1).
  * As with sgm_set_overlap_post a result is complete after sgm_synchronize / sgm_match_wait, not in stream order of
  * sgm_stream(s).  Ignored in row-tile mode.  The instance must be idle (the call waits for it). */
 enum { SGM_STAGE_MAIN = 0, SGM_STAGE_SUM = 1, SGM_STAGE_POST = 2 };
 bool          sgm_set_stage_cus(sgm_instance* s, int which, int first_cu_per_xcd, int cus_per_xcd);
 /* The same with a dispatch priority instead of a CU range: the group gets a stream of its own on all CUs whose waiting
  * workgroups the dispatcher serves before (priority < 0) or after (> 0) those of normal streams (clamped to the device's
- * range).  Replaces a CU range set before. */
+ * range).  Replaces a CU range set before; a later sgm_set_stage_cus (count >= 0) replaces the priority stream in turn, and
+ * count < 0 goes back to the default in either case. */
 bool          sgm_set_stage_priority(sgm_instance* s, int which, int priority);
 /* The HIP stream (hipStream_t as void*) the instance launches on, e.g. to record events. */
 void*         sgm_stream(sgm_instance* s);

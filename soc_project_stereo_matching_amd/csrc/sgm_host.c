@@ -44,6 +44,9 @@ struct sgm_instance {
     bool post_pending;           /* a post pass is (possibly) still running on post_stream */
     void* tail_stream;           /* the stream the last match's final kernel was queued on (NULL: stream) */
     int cu_first[3], cu_count[3];/* CUs per XCD of the main / sum / post stream (count 0: all CUs) */
+    int env_lanes, env_hl, env_agg_fast, env_fused;   /* SGM_LANES_PER_PIXEL, SGM_HL, SGM_AGG_FAST, SGM_FUSED_WTA as read at sgm_create
+                                    (-1: not set) -- tuning / test knobs, not looked up again on the per-frame sgm_reset path */
+    bool stage_prio[3];          /* that stream was made by sgm_set_stage_priority (an all-CU request must replace it, not keep it) */
     int* h_status;               /* page-locked word the chained median kernel sets when a band gave up waiting (sgmd_median) */
     void* timer;
     int timing;
@@ -208,6 +211,12 @@ static bool device_usable(int device)
     return true;
 }
 
+static int env_int(const char* name)
+{
+    const char* e = getenv(name);
+    return (e && *e) ? atoi(e) : -1;
+}
+
 sgm_instance* sgm_create(int device)
 {
     if (!device_usable(device)) return NULL;
@@ -220,6 +229,10 @@ sgm_instance* sgm_create(int device)
     if (sgmd_alloc_pinned(device, &st, 64) != 0) { sgmd_stream_destroy(device, s->stream); free(s); return NULL; }
     s->h_status = (int*)st;
     *s->h_status = 0;
+    s->env_lanes = env_int("SGM_LANES_PER_PIXEL");
+    s->env_hl = env_int("SGM_HL");
+    s->env_agg_fast = env_int("SGM_AGG_FAST");
+    s->env_fused = env_int("SGM_FUSED_WTA");
     return s;
 }
 
@@ -290,9 +303,10 @@ bool sgm_set_stage_cus(sgm_instance* s, int which, int first_per_xcd, int count_
         *slot = NULL;
         if (which == SGM_STAGE_POST) s->overlap_post = 0;
         s->cu_first[which] = s->cu_count[which] = 0;
+        s->stage_prio[which] = false;
         return true;
     }
-    if (*slot && s->cu_first[which] == first_per_xcd && s->cu_count[which] == count_per_xcd) {
+    if (*slot && !s->stage_prio[which] && s->cu_first[which] == first_per_xcd && s->cu_count[which] == count_per_xcd) {
         if (which == SGM_STAGE_POST) s->overlap_post = 1;
         return true;
     }
@@ -302,6 +316,7 @@ bool sgm_set_stage_cus(sgm_instance* s, int which, int first_per_xcd, int count_
     *slot = fresh;
     s->cu_first[which] = first_per_xcd;
     s->cu_count[which] = count_per_xcd;
+    s->stage_prio[which] = false;
     if (which == SGM_STAGE_POST) s->overlap_post = 1;
     return true;
 }
@@ -317,6 +332,7 @@ bool sgm_set_stage_priority(sgm_instance* s, int which, int priority)
     if (*slot) sgmd_stream_destroy(s->device, *slot);
     *slot = fresh;
     s->cu_first[which] = s->cu_count[which] = 0;
+    s->stage_prio[which] = true;
     if (which == SGM_STAGE_POST) s->overlap_post = 1;
     return true;
 }
@@ -615,8 +631,7 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
      * fewest instructions per cell; a single frame keeps 16 lanes per pixel for the shorter serial step (measured
      * at KITTI size, one frame: 16 lanes + 32-lane horizontals 0.35 ms, 8 lanes + 32-lane horizontals 0.39 ms, 8 lanes 0.59 ms) */
     {
-        const char* e = getenv("SGM_LANES_PER_PIXEL");
-        const int want = (e && *e) ? atoi(e) : (s->batch >= 2 ? 8 : 16);
+        const int want = s->env_lanes >= 0 ? s->env_lanes : (s->batch >= 2 ? 8 : 16);      /* SGM_LANES_PER_PIXEL */
         /* negative P1 (defined by the reference's C arithmetic, covered by the parity tests, used by nobody) runs the
          * generic aggregation step, which only exists for 16 lanes per pixel */
         /* the wide census windows feed the aggregation from a cost volume: generic step, 16 lanes per pixel */
@@ -629,10 +644,9 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
      * the launch's longest chains for 4 % more instructions in total) -- KITTI 3850 -> 4010 fps through host pointers, aggregation
      * 1.19 -> 1.16 ms per 8 frames alone; 32 and 64 lanes cost more than they shorten (round 2) */
     {
-        const char* e = getenv("SGM_HL");
         const int ok64 = (s->g.Dp % 64 == 0) && (s->g.Dp / 64 == 2 || s->g.Dp / 64 == 4 || s->g.Dp / 64 == 8);
         const int ok32 = (s->g.Dp % 32 == 0) && (s->g.Dp / 32 == 2 || s->g.Dp / 32 == 4 || s->g.Dp / 32 == 8 || s->g.Dp / 32 == 16);
-        int want = (e && *e) ? atoi(e) : ((s->batch == 1 || s->g.LPP == 16) ? 32 : 16);   /* D > 128 in batches (16 lanes elsewhere): 32, +2 % at 2880x1988 D=256 */
+        int want = s->env_hl >= 0 ? s->env_hl : ((s->batch == 1 || s->g.LPP == 16) ? 32 : 16);   /* SGM_HL; */   /* D > 128 in batches (16 lanes elsewhere): 32, +2 % at 2880x1988 D=256 */
         const int ok16 = s->g.LPP == 8 && (s->g.Dp / 16 == 2 || s->g.Dp / 16 == 4 || s->g.Dp / 16 == 8 || s->g.Dp / 16 == 16);
         if (want == 64 && !ok64) want = 32;
         if (want == 32 && !ok32) want = 0;
@@ -660,8 +674,7 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
         build_p2_table(option->p1, option->p2_init, lut);
         s->paths.pen_max = 0;
         for (int a = 0; a < 256; ++a) if (lut[a] > s->paths.pen_max) s->paths.pen_max = lut[a];
-        const char* e = getenv("SGM_AGG_FAST");                  /* 0: keep the plain non-negative-P1 step (parity tests run both) */
-        s->paths.allow_fast = (e && *e) ? atoi(e) != 0 : 1;
+        s->paths.allow_fast = s->env_agg_fast >= 0 ? s->env_agg_fast != 0 : 1;   /* SGM_AGG_FAST=0: keep the plain non-negative-P1 step (parity tests run both) */
     }
     for (int d = 0; d < 8; ++d) {
         s->paths.dx[d] = k_dir_dx[d];
@@ -707,11 +720,10 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
     s->s_is_zero = true;                                         /* .c:57: memset of cost_aggr, done lazily */
     s->s_pending = false;
     {
-        const char* e = getenv("SGM_FUSED_WTA");
         /* one workgroup per image row segment (the launcher cuts rows into up to 4 segments when a launch has few rows);
          * at KITTI size: a batch of 8 frames 0.093 ms per frame against 0.115 + 0.043 for the two separate kernels, a
          * single frame 0.144 against 0.163 */
-        const int want = (e && *e) ? atoi(e) != 0 : 1;
+        const int want = s->env_fused >= 0 ? s->env_fused != 0 : 1;        /* SGM_FUSED_WTA */
         s->fused_wta = sgmd_sum_wta_lr_supported(&s->g, s->row_cap) && want;
     }
     s->have_ms = false;

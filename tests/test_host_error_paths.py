@@ -475,6 +475,30 @@ def test_stage_streams_ordering(host):
     L.sgm_destroy(s)
 
 
+def test_a_priority_stream_is_replaced_by_a_later_all_cu_request(host):
+    """sgm_set_stage_priority stores no CU range; a later sgm_set_stage_cus(which, 0, 0) -- 'own stream, all CUs, normal
+    priority' -- and, for the main group, count < 0 ('back to the default') must make a new stream instead of finding the
+    request 'already configured' and keeping the priority stream."""
+    L = host
+    L.sgm_set_stage_cus.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.sgm_set_stage_cus.restype = C.c_bool
+    L.sgm_set_stage_priority.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.sgm_set_stage_priority.restype = C.c_bool
+    s, opt = fresh(L)
+    for which in (1, 0):
+        L.stub_clear()
+        assert L.sgm_set_stage_priority(s, which, -1)
+        assert L.sgm_set_stage_cus(s, which, 0, 0)                        # replaces the priority stream ...
+        assert L.sgm_set_stage_cus(s, which, 0, 0)                        # ... and only then is it "already configured"
+        assert [(n, a) for n, a in log(L) if n.startswith("stream_")] == [("stream_prio", -1), ("stream_cus", 0)]
+    L.stub_clear()
+    assert L.sgm_set_stage_priority(s, 0, 1) and L.sgm_set_stage_cus(s, 0, 0, -1)          # main group: default = a plain all-CU stream
+    assert [(n, a) for n, a in log(L) if n.startswith("stream_")] == [("stream_prio", 1), ("stream_cus", 0)]
+    f = Frame()
+    assert L.sgm_reset(s, 48, 20, C.byref(opt)) and L.sgm_match_device(s, *f.args())
+    L.sgm_destroy(s)
+
+
 def test_median_band_that_gave_up_fails_the_match(host):
     """The chained median kernel of tall frames polls the band above a bounded number of times; a band that gives up sets a word
     of page-locked host memory (sgmd_median's status argument).  The host reads it after every wait for the streams: the
