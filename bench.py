@@ -997,7 +997,7 @@ def run_frames(args):
                                          ("middlebury_2880x1988_d256_p8", 2, 2, 8), ("drivingstereo_1762x800_d192_p8", 8, 2, 8),
                                          ("kitti_1242x375_d128_p8_nospeckle", 8, 2, 20)):
                     try:
-                        wl.append(device_resident_leg(S, torch, local_rank, name, wb, wf, ws, 3, honor4=name.endswith("_p4")))
+                        wl.append(device_resident_leg(S, torch, local_rank, name, wb, wf, ws, 3, honor4=name.endswith("_p4"), alone=True))
                     except Exception as e:                       # one workload must not take the line down
                         wl.append({"workload": name, "error": repr(e)})
                 line["workloads"] = wl
