@@ -165,6 +165,11 @@ bool          sgm_set_stage_cus(sgm_instance* s, int which, int first_cu_per_xcd
 bool          sgm_set_stage_priority(sgm_instance* s, int which, int priority);
 /* The HIP stream (hipStream_t as void*) the instance launches on, e.g. to record events. */
 void*         sgm_stream(sgm_instance* s);
+/* Whether the LAST match ran the fused last sweep (csrc/sgm_upsum.hip: the three upward directions computed inside the cost-sum /
+ * winner-take-all kernel, their planes never written): image rows per workgroup of that kernel, 0 = the separate kernels.  It is used
+ * for batches of whole frames with W > H, a padded range of 128, eight paths and P1 >= 0 when SGM_UPSUM allows it, and only by
+ * matches that neither add to an earlier S (Q14) nor keep stages; results are identical either way. */
+int           sgm_fused_sweep_rows(const sgm_instance* s);
 
 /* Batches: after sgm_set_batch(s, n) and the next sgm_initialize / sgm_reset, every sgm_match /
  * sgm_match_device call processes n frames of the same shape stored back to back ([n][H][W] for the

@@ -32,11 +32,27 @@ static int aggregate_any(int ord, void* stream, const sgmd_geom* g, const sgmd_p
     // SGM_DIR_MASK (diagnostics only: wrong results): run a subset of the directions, to time them apart; bit 8 = the anomalous lines
     static const int debug_mask = getenv("SGM_DIR_MASK") ? (int)strtol(getenv("SGM_DIR_MASK"), nullptr, 0) : 0x1FF;
     int blocks = 0;
+    a.post_wrap_mask = 0;
+    // the fused last sweep (sgmd_upsum) computes the upward directions itself, except the cells of the diagonal lines BEHIND their
+    // wrap around the image edge (W > H: line i of (1,-1) visits (H-1-k, (i+k) mod W) and wraps iff i >= W-H+1; line i of (-1,-1)
+    // visits (H-1-k, (i-k) mod W) and wraps iff i <= H-2)
+    const bool up_fused = paths->up_fused && g->W > g->H && g->row_begin == 0 && g->row_end == g->H;
     for (int d = 0; d < 8; ++d) {
         a.dx[d] = paths->dx[d]; a.dy[d] = paths->dy[d]; a.anom_line[d] = paths->anom_line[d];
         a.block_begin[d] = blocks;
-        if (d < paths->ndirs && ((paths->dir_mask & debug_mask) >> d) & 1) {
-            const int nlines = (paths->dy[d] == 0) ? g->row_end - g->row_begin : g->W;
+        a.line_lo[d] = 0;
+        a.line_n[d] = g->W;
+        bool run = d < paths->ndirs && ((paths->dir_mask & debug_mask) >> d) & 1;
+        if (up_fused && paths->dy[d] == -1) {
+            if (paths->dx[d] == 0) run = false;
+            else {
+                a.line_lo[d] = paths->dx[d] > 0 ? g->W - g->H + 1 : 0;
+                a.line_n[d] = g->H - 1;
+                a.post_wrap_mask |= 1 << d;
+            }
+        }
+        if (run) {
+            const int nlines = (paths->dy[d] == 0) ? g->row_end - g->row_begin : a.line_n[d];
             const int lines_per_wave = 64 / ((paths->dy[d] == 0 && g->HL) ? g->HL : g->LPP);
             blocks += (nlines + lines_per_wave - 1) / lines_per_wave;
         }

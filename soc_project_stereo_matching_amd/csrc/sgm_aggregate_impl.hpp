@@ -46,6 +46,11 @@ struct AggArgs {
     int block_begin[9];
     int ghost_zero;
     int strips;                 // XCD-aware numbering of the workgroups (see sgm_aggregate_k): XCDs per frame, 1 = plain numbering
+    // the fused last sweep (sgm_upsum.hip) computes the upward directions itself except the POST-wrap cells of the diagonal lines that
+    // wrap around the image edge: for those directions this launch walks only lines [line_lo, line_lo + line_n) and stores only
+    // what lies behind the wrap (post_wrap_mask: bit d).  Everything else: line_lo = 0, line_n = all lines, mask 0.
+    int line_lo[8], line_n[8];
+    int post_wrap_mask;
 };
 
 // per-frame base pointers of a batched launch (kept apart from the kernel-argument struct so that struct
@@ -325,14 +330,16 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
     const int rows = a.row_end - a.row_begin;
     const int skip = (KIND == AGG_H) ? 0 : (fwd ? a.row_begin : H - a.row_end);    // rows between that edge and the tile
     const bool import_state = skip > 0;
-    const int nlines = (KIND == AGG_H) ? rows : W;                         // ref :238
+    const int nlines = (KIND == AGG_H) ? rows : a.line_lo[dir] + a.line_n[dir];   // ref :238 (W lines; a subset for the fused last sweep)
+    const bool pwo = (KIND == AGG_D) && ((a.post_wrap_mask >> dir) & 1);   // store only behind the line's wrap
+    bool wrapped = false;
     const int nsteps = (KIND == AGG_H) ? W - 1 : (import_state ? rows : rows - 1);   // ref :281
     if (KIND == AGG_D && W < 2) return;                                    // the only line is the anomalous one
 
     constexpr int LPW = 64 / LPP;                                          // path lines per wave
     const int sub = lane & (LPP - 1);
     const bool first_lane = (sub == 0), last_lane = (sub == LPP - 1);
-    int line = grp * LPW + lane / LPP;
+    int line = ((KIND == AGG_H) ? 0 : a.line_lo[dir]) + grp * LPW + lane / LPP;
     bool store_ok = line < nlines;
     if (!store_ok) line = nlines - 1;                                      // keep the wave convergent; stores are masked
     if (KIND == AGG_D && line == a.anom_line[dir]) {                       // handled by agg_anomalous()
@@ -393,6 +400,7 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
             off += (unsigned)dstep_off;
         } else if (WIDE) {
             const bool wrap = (pcol == wrap_at);
+            wrapped = wrapped || wrap;
             pcol = wrap ? wrap_to : pcol + (unsigned)col_step;
             p += wrap ? pstep_w : pstep_n;
             off += wrap ? ostep_w : ostep_n;
@@ -466,7 +474,7 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
 #pragma unroll
         for (int j = 1; j < NP; ++j) m = pk_min(m, Lp[j]);
         min_prev = row_allmin<LPP>(min(as_u(m) & 0xFFFFu, as_u(m) >> 16));
-        if (store_ok) {
+        if (store_ok && !pwo) {
             CellVec<DPL> o;
             pack_cells<DPL>(Lp, o);
             store_cells<DPL>(plane + off, o);
@@ -482,14 +490,16 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
     uint8_t gb[PF];
     int limb[PF];
     unsigned ob[PF];
+    bool wb[PF];                                                           // the slot's pixel lies behind the line's wrap
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
-        gb[u] = 0; ob[u] = off; clb[u] = 0; limb[u] = 0;
+        gb[u] = 0; ob[u] = off; clb[u] = 0; limb[u] = 0; wb[u] = false;
 #pragma unroll
         for (int i = 0; i < DPL; ++i) cb[u].r[i] = 0;
         if (1 + u <= nsteps) {
             advance();
             ob[u] = off;
+            wb[u] = wrapped;
             limb[u] = x - lim_bias;
             fetch(cb[u], clb[u], gb[u]);
         }
@@ -503,6 +513,7 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
         const int g = (int)gb[u];
         const int lim = limb[u];
         const unsigned o = ob[u];
+        const bool st_ok = store_ok && (!pwo || wb[u]);
         const unsigned dg = __builtin_amdgcn_sad_u8((unsigned)g, (unsigned)g_prev, 0u);   // |g - g_prev| (grey values: one byte)
         CellVec<DPL> packed;
         if constexpr (NN) {
@@ -511,6 +522,7 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
             if (refill) {                                                      // the slot's census words are consumed now
                 advance();
                 ob[u] = off;
+                wb[u] = wrapped;
                 limb[u] = x - lim_bias;
                 fetch(cb[u], clb[u], gb[u]);
             }
@@ -521,13 +533,14 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
             if (refill) {
                 advance();
                 ob[u] = off;
+                wb[u] = wrapped;
                 limb[u] = x - lim_bias;
                 fetch(cb[u], clb[u], gb[u]);
             }
             min_prev = agg_step<DPL, PAD, LPP>(C, Lp, min_prev, lut_s[dg], p1v, padmask, first_lane, last_lane, packed);
         }
         g_prev = g;
-        if (store_ok) store_cells<DPL>(plane + o, packed);
+        if (st_ok) store_cells<DPL>(plane + o, packed);
     };
     // Everything the prologue has in flight lands before the hot loop (once per line).  The waits inside the loop are placed for
     // the state merged over BOTH ways into the loop head; with the prologue's loads still pending in whatever order the scheduler

@@ -88,6 +88,8 @@ typedef struct {
     int allow_fast;            /* 0: never the FAST step family (sgm_aggregate_fast.hip), whatever the penalties (tests run both) */
     int dir_mask;              /* bit d: run direction d in this launch (0xFF normally; a tile sweep runs a subset) */
     int run_anom;              /* 1: run the anomalous diagonal lines in this launch (whole frame, never tiled) */
+    int up_fused;              /* 1: the upward directions belong to the fused last sweep (sgmd_upsum): this launch skips (0,-1) and walks
+                                  of (-1,-1) / (1,-1) only the H-1 lines that wrap around the image edge, storing their post-wrap cells */
 } sgmd_paths;
 
 /* ---- stage launchers (all asynchronous on `stream`) ---- */
@@ -139,6 +141,19 @@ int sgmd_sum_wta_lr_supported(const sgmd_geom* g, int row_cap);   /* row_cap: mo
 int sgmd_sum_wta_lr(int ord, void* stream, const sgmd_geom* g, int ndirs, const void* planes, size_t plane_bytes,
                     const void* extras, const void* row_extras, const void* row_extra_count, int row_cap, int accumulate,
                     int store_S, int do_right, void* S, int check_unique, float one_minus_ratio, void* disp_l, void* disp_r);
+
+/* The LAST vertical sweep -- directions (0,-1), (-1,-1), (1,-1), SemiGlobalMatching.c:216,218,219 -- fused with the cost sum and both
+ * winner-take-all passes (sgm_upsum.hip): reads the five other planes and the post-wrap cells of the two diagonal ones (an
+ * aggregation launch with paths->up_fused), writes the two disparity maps; S and the three planes never exist.
+ * sgmd_upsum_rows: the most image rows a workgroup may take (sgmd_upsum's rows_per_workgroup: 1 .. that), 0 where the shape keeps the separate kernels (needs W > H, Dp = 128, whole frames).
+ * scratch: sgmd_upsum_scratch_bytes(g) bytes, zero when allocated; generation: a different number for every launch on that scratch;
+ * status: NULL or a page-locked int set to 1 if a workgroup gave up waiting for the rows below (the maps are then wrong). */
+int sgmd_upsum_rows(const sgmd_geom* g);
+size_t sgmd_upsum_scratch_bytes(const sgmd_geom* g);
+int sgmd_upsum(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* paths, const void* img_left, const void* census_l,
+               const void* census_r, const void* lut, const void* planes, size_t plane_bytes, const void* extras,
+               const void* row_extras, const void* row_extra_count, int row_cap, int do_right, int check_unique, float one_minus_ratio,
+               void* scratch, unsigned generation, void* status, int rows_per_workgroup, void* disp_l, void* disp_r);
 
 /* right-view winner-take-all on S[y][x+d][d] (SemiGlobalMatching.c:395-408) -> disp_r; needed by the LR check only */
 int sgmd_wta_right(int ord, void* stream, const sgmd_geom* g, const void* S, int check_unique, float one_minus_ratio,

@@ -44,6 +44,16 @@ struct sgm_instance {
     bool post_pending;           /* a post pass is (possibly) still running on post_stream */
     void* tail_stream;           /* the stream the last match's final kernel was queued on (NULL: stream) */
     int cu_first[3], cu_count[3];/* CUs per XCD of the main / sum / post stream (count 0: all CUs) */
+    int up_rows;                 /* > 0: the last vertical sweep (directions (0,-1), (-1,-1), (1,-1)) runs fused with the cost sum and both WTAs
+                                    (sgmd_upsum) wherever a match allows it: image rows per workgroup of that kernel */
+    void* d_up_scratch;          /* its hand-over rows, progress words and tickets */
+    size_t cap_up_scratch;
+    void* d_left_keep;           /* copy of the last fused match's left image(s): what re-creating the three planes needs (Q14, stage read-back) */
+    size_t cap_left_keep;
+    unsigned up_gen;             /* launch counter of the fused kernel (its progress words carry it) */
+    int last_up_rows;            /* rows per workgroup of the fused sweep in the LAST match, 0 if it ran the separate kernels */
+    bool planes_partial;         /* the planes of the last frame lack the upward directions: materialize_S re-creates them first */
+    int env_upsum, env_upsum_rows;   /* SGM_UPSUM, SGM_UPSUM_ROWS */
     int env_lanes, env_hl, env_agg_fast, env_fused;   /* SGM_LANES_PER_PIXEL, SGM_HL, SGM_AGG_FAST, SGM_FUSED_WTA as read at sgm_create
                                     (-1: not set) -- tuning / test knobs, not looked up again on the per-frame sgm_reset path */
     bool stage_prio[3];          /* that stream was made by sgm_set_stage_priority (an all-CU request must replace it, not keep it) */
@@ -112,6 +122,7 @@ struct sgm_instance {
     void* ev_chunk[4];
     int async_chunks;
 };
+#define UPSUM_DEFAULT 0       /* the fused last sweep is opt-in (SGM_UPSUM=1) until it beats the separate kernels in the timed pipeline */
 #define RESULT_CHUNKS 4
 #define RESULT_CHUNK_MIN ((size_t)256 << 10)      /* smaller results are not worth the events */
 #define RESULT_CHUNK_SPLIT ((size_t)4 << 20)      /* below this: two pieces */
@@ -233,6 +244,8 @@ sgm_instance* sgm_create(int device)
     s->env_hl = env_int("SGM_HL");
     s->env_agg_fast = env_int("SGM_AGG_FAST");
     s->env_fused = env_int("SGM_FUSED_WTA");
+    s->env_upsum = env_int("SGM_UPSUM");
+    s->env_upsum_rows = env_int("SGM_UPSUM_ROWS");
     return s;
 }
 
@@ -243,7 +256,8 @@ static void free_device_buffers(sgm_instance* s)
     void** all[] = {&s->d_left, &s->d_right, &s->d_census_l, &s->d_census_r_alloc, &s->d_cost, &s->d_planes_alloc, &s->d_extras,
                     &s->d_S, &s->d_disp, &s->d_disp_r, &s->d_labels, &s->d_sizes, &s->d_lut, &s->d_row_extras,
                     &s->d_row_count, &s->d_snap_wta, &s->d_snap_lr, &s->d_snap_speckle, &s->d_totals,
-                    &s->d_median_scratch, &s->d_census64_l, &s->d_census64_r, &s->d_bgr, &s->d_depth, &s->d_census_need};
+                    &s->d_median_scratch, &s->d_census64_l, &s->d_census64_r, &s->d_bgr, &s->d_depth, &s->d_census_need,
+                    &s->d_up_scratch, &s->d_left_keep};
     for (size_t i = 0; i < sizeof all / sizeof all[0]; ++i) {
         sgmd_free(s->device, *all[i]);
         *all[i] = NULL;
@@ -255,6 +269,7 @@ static void free_device_buffers(sgm_instance* s)
     s->h_left = s->h_right = s->h_disp = s->h_bgr = NULL;
     s->cap_px = s->cap_planes = s->cap_S = s->cap_cost = s->cap_extras = s->cap_median = s->cap_census64 = s->cap_bgr = 0;
     s->cap_census_need = 0;
+    s->cap_up_scratch = s->cap_left_keep = 0;
     s->need_key[0] = 0;
     s->cap_H = s->cap_row_cap = 0;
     s->tab_W = s->tab_H = 0;
@@ -371,6 +386,7 @@ void sgm_select_frame(sgm_instance* s, int frame)
     if (s && frame >= 0 && frame < s->batch) s->read_frame = frame;
 }
 void* sgm_stream(sgm_instance* s) { return s ? s->stream : NULL; }
+int sgm_fused_sweep_rows(const sgm_instance* s) { return s ? s->last_up_rows : 0; }
 
 void sgm_enable_timing(sgm_instance* s, int enable)
 {
@@ -726,6 +742,15 @@ bool sgm_initialize(sgm_instance* s, uint16_t width, uint16_t height, const SGMO
         const int want = s->env_fused >= 0 ? s->env_fused != 0 : 1;        /* SGM_FUSED_WTA */
         s->fused_wta = sgmd_sum_wta_lr_supported(&s->g, s->row_cap) && want;
     }
+    /* the fused last sweep: batches of whole frames with eight paths and non-negative P1 on the census path (sgm_upsum.hip has
+     * the shapes: W > H, Dp = 128).  SGM_UPSUM=0 / 1 forces it off / on (also for one frame per launch, where its row-to-row chain
+     * costs latency) */
+    s->up_rows = 0;
+    s->planes_partial = false;
+    if (s->fused_wta && s->tile_end == 0 && !s->census_w && s->paths.ndirs == 8 && option->p1 >= 0 && s->row_cap <= 8 &&
+        (s->env_upsum >= 0 ? s->env_upsum != 0 : UPSUM_DEFAULT && s->batch >= 2))
+        s->up_rows = sgmd_upsum_rows(&s->g);
+    if (s->up_rows > 0 && s->env_upsum_rows >= 1 && s->env_upsum_rows < s->up_rows) s->up_rows = s->env_upsum_rows;
     s->have_ms = false;
     s->initialized = true;
     return true;
@@ -744,6 +769,9 @@ static void mark_on(sgm_instance* s, void* stream, int idx)
 }
 static void mark(sgm_instance* s, int idx) { mark_on(s, s->stream, idx); }
 
+static int sweep_mask(const sgm_instance* s, int forward);
+static int launch_aggregation(sgm_instance* s, const sgmd_paths* paths, const void* d_left);
+
 /* d_S <- [d_S +] sum of the planes of the last frame, if the fused kernel skipped that store */
 static int materialize_S(sgm_instance* s)
 {
@@ -753,6 +781,16 @@ static int materialize_S(sgm_instance* s)
      * pass still running on its own stream comes first */
     if (s->sum_pending && sgmd_stream_wait_event(s->device, s->stream, s->ev_sum) != 0) return -1;
     if (s->post_pending && sgmd_stream_wait_event(s->device, s->stream, s->ev_post) != 0) return -1;
+    if (s->planes_partial) {
+        /* the last match ran the fused sweep: the three upward planes do not exist.  Walk those directions now (the census images
+         * and the kept copy of the left image are still that frame's; the anomalous lines and their cells were done then) */
+        sgmd_paths p = s->paths;
+        p.dir_mask = sweep_mask(s, 0);
+        p.run_anom = 0;
+        p.up_fused = 0;
+        if (launch_aggregation(s, &p, s->d_left_keep) != 0) return -1;
+        s->planes_partial = false;
+    }
     /* the left-view WTA this kernel also produces goes to a dead scratch map (speckle labels) */
     const int rc = sgmd_sum_wta(s->device, s->stream, &s->g, s->paths.ndirs, s->d_planes, s->plane_bytes, s->d_extras,
                                 s->d_row_extras, s->d_row_count, s->row_cap, s->s_pending_accumulate ? 1 : 0, s->d_S, 0, 0.0f,
@@ -859,6 +897,28 @@ static int lr_stage(sgm_instance* s, void* st, void* d_out)
  * pending planes) still describe exactly the matches that completed, so a later Match without Reset (Q14) accumulates
  * onto the right thing. */
 #define LAUNCH(expr) do { if ((expr) != 0) goto failed; } while (0)
+/* scratch of the fused last sweep (zero when allocated: its progress words start below every generation) and the kept left image */
+static int ensure_upsum(sgm_instance* s)
+{
+    const size_t need = sgmd_upsum_scratch_bytes(&s->g), px = (size_t)s->g.B * s->g.W * s->g.H;
+    if (need > s->cap_up_scratch || !s->d_up_scratch) {
+        sync_streams(s);
+        sgmd_free(s->device, s->d_up_scratch);
+        s->d_up_scratch = NULL; s->cap_up_scratch = 0;
+        if (sgmd_alloc(s->device, &s->d_up_scratch, need) != 0) return -1;
+        if (sgmd_memset_async(s->device, s->stream, s->d_up_scratch, 0, need) != 0) return -1;
+        s->cap_up_scratch = need;
+    }
+    if (px > s->cap_left_keep || !s->d_left_keep) {
+        sync_streams(s);
+        sgmd_free(s->device, s->d_left_keep);
+        s->d_left_keep = NULL; s->cap_left_keep = 0;
+        if (sgmd_alloc(s->device, &s->d_left_keep, px) != 0) return -1;
+        s->cap_left_keep = px;
+    }
+    return 0;
+}
+
 static bool run_pipeline(sgm_instance* s, const void* d_left, const void* d_right, void* d_out)
 {
     const int dev = s->device;
@@ -887,7 +947,18 @@ static bool run_pipeline(sgm_instance* s, const void* d_left, const void* d_righ
     if (s->need_plane_memset && s->paths.ndirs > 4)
         for (int f = 0; f < g->B; ++f)
             LAUNCH(sgmd_memset_async(dev, st, (char*)s->d_planes_alloc + ((size_t)f * 8 + 4) * s->plane_bytes, 0, 4 * s->plane_bytes));
-    LAUNCH(launch_aggregation(s, &s->paths, d_left));                                               /* .c:94 */
+    /* the last vertical sweep fused with the cost sum (sgmd_upsum): whenever this match neither adds to an earlier S (Q14) nor has
+     * to leave S behind for a test */
+    const bool use_up = s->up_rows > 0 && !s->keep_stages && s->s_is_zero && s->fused_wta;
+    s->last_up_rows = use_up ? s->up_rows : 0;
+    if (use_up) {
+        LAUNCH(ensure_upsum(s));
+        LAUNCH(sgmd_d2d_async(dev, st, s->d_left_keep, d_left, (size_t)g->B * g->W * g->H));
+        sgmd_paths p = s->paths;
+        p.up_fused = 1;
+        LAUNCH(launch_aggregation(s, &p, d_left));
+    } else
+        LAUNCH(launch_aggregation(s, &s->paths, d_left));                                           /* .c:94 */
     mark(s, 3);
     if (own_sum) {
         LAUNCH(sgmd_event_record(dev, s->ev_agg, st));
@@ -897,7 +968,17 @@ static bool run_pipeline(sgm_instance* s, const void* d_left, const void* d_righ
     /* the cost sum writes d_out and the right-view map, which the previous match's post pass may still be reading */
     if (s->post_pending) LAUNCH(sgmd_stream_wait_event(dev, sts, s->ev_post));
     mark_on(s, sts, M_SUM_BEGIN);
-    LAUNCH(sum_and_wta(s, sts, d_out, true));                                                       /* .c:94 sum, .c:99, .c:105 */
+    if (use_up) {
+        LAUNCH(sgmd_upsum(dev, sts, g, &s->paths, s->d_left_keep, s->d_census_l, s->d_census_r, s->d_lut, s->d_planes, s->plane_bytes, s->d_extras,
+                          s->d_row_extras, s->d_row_count, s->row_cap, (o->is_check_lr || s->reference_view) ? 1 : 0, o->is_check_unique ? 1 : 0,
+                          1 - o->uniqueness_ratio, s->d_up_scratch, ++s->up_gen, s->h_status, s->up_rows, d_out, s->d_disp_r));
+        s->planes_partial = true;                                /* S of this frame = five planes + what materialize_S re-creates */
+        s->s_pending = true;
+        s->s_pending_accumulate = false;
+        s->s_is_zero = false;
+        mark_on(s, sts, 4);
+    } else
+        LAUNCH(sum_and_wta(s, sts, d_out, true));                                                   /* .c:94 sum, .c:99, .c:105 */
     if (s->keep_stages) LAUNCH(sgmd_d2d_async(dev, sts, s->d_snap_wta, d_out, px_bytes));
     mark_on(s, sts, 5);
     /* the post pass (latency-bound kernels that fill a fraction of the GPU) on its own stream, so that the stream(s) before it

@@ -391,6 +391,12 @@ class SGMInstance(_StageReader):
     def keep_stages(self, enable=True):
         self.lib.sgm_keep_stages(self.handle, int(enable))
 
+    def fused_sweep_rows(self) -> int:
+        """Rows per workgroup of the fused last sweep in the LAST match, 0 if it ran the separate kernels."""
+        self.lib.sgm_fused_sweep_rows.argtypes = [C.c_void_p]
+        self.lib.sgm_fused_sweep_rows.restype = C.c_int
+        return int(self.lib.sgm_fused_sweep_rows(self.handle))
+
     def enable_timing(self, enable=True):
         self.lib.sgm_enable_timing(self.handle, int(enable))
 

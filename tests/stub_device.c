@@ -155,7 +155,7 @@ int sgmd_lrcheck_right(int o, void* st, const sgmd_geom* g, const void* dr, cons
 size_t sgmd_census_slack(const sgmd_geom* g) { return ((size_t)g->dmin + g->Dp + 8) * 4; }
 int sgmd_aggregate(int o, void* st, const sgmd_geom* g, const sgmd_paths* p, const void* img, const void* cl, const void* cr,
                    const void* lut, void* planes, size_t pb, void* ex)
-{ (void)o; (void)st; (void)cl; (void)cr; (void)lut; (void)ex; if (g_toy) toy_aggregate(g, p, (const unsigned char*)img, planes, pb); return note("aggregate", p->dir_mask); }
+{ (void)o; (void)st; (void)cl; (void)cr; (void)lut; (void)ex; if (g_toy) toy_aggregate(g, p, (const unsigned char*)img, planes, pb); return note("aggregate", p->dir_mask | (p->up_fused ? 0x100 : 0)); }
 int sgmd_sum_wta(int o, void* st, const sgmd_geom* g, int nd, const void* pl, size_t pb, const void* ex, const void* re,
                  const void* rc, int cap, int accumulate, void* S, int cu, float omr, void* dl)
 { (void)o; (void)st; (void)g; (void)nd; (void)pl; (void)pb; (void)ex; (void)re; (void)rc; (void)cap; (void)S; (void)cu; (void)omr; (void)dl;
@@ -166,6 +166,15 @@ int sgmd_sum_wta_lr(int o, void* st, const sgmd_geom* g, int nd, const void* pl,
 { (void)o; (void)st; (void)ex; (void)re; (void)rc; (void)cap; (void)do_right; (void)S; (void)cu; (void)omr; (void)dr;
   if (g_toy) toy_sum(g, nd, pl, pb, dl);
   return note("sum_wta_lr", accumulate | (store_S << 1)); }
+/* the fused last sweep: logged with the rows per workgroup; the aggregation launch in front of it is logged by sgmd_aggregate */
+int sgmd_upsum_rows(const sgmd_geom* g) { return (g->Dp == 128 && g->W > g->H && g->row_begin == 0 && g->row_end == g->H) ? 3 : 0; }
+size_t sgmd_upsum_scratch_bytes(const sgmd_geom* g) { return sgmd_upsum_rows(g) ? (size_t)g->B * 6 * g->W * g->Dp + 4096 : 0; }
+int sgmd_upsum(int o, void* st, const sgmd_geom* g, const sgmd_paths* p, const void* img, const void* cl, const void* cr, const void* lut,
+               const void* pl, size_t pb, const void* ex, const void* re, const void* rc, int cap, int do_right, int cu, float omr,
+               void* scratch, unsigned gen, void* status, int rows, void* dl, void* dr)
+{ (void)o; (void)st; (void)g; (void)p; (void)img; (void)cl; (void)cr; (void)lut; (void)pl; (void)pb; (void)ex; (void)re; (void)rc; (void)cap;
+  (void)do_right; (void)cu; (void)omr; (void)scratch; (void)gen; (void)status; (void)dl; (void)dr;
+  return note("upsum", rows); }
 int sgmd_wta_right(int o, void* st, const sgmd_geom* g, const void* S, int cu, float omr, void* dr)
 { (void)o; (void)st; (void)g; (void)S; (void)cu; (void)omr; (void)dr; return note("wta_right", 0); }
 int sgmd_lrcheck(int o, void* st, const sgmd_geom* g, void* dl, const void* dr, float th)
