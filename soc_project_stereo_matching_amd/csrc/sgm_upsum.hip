@@ -44,6 +44,7 @@ struct UpArgs {
     unsigned* progress;         // [B][ngroups]: (generation << 13) + iterations the workgroup's top team has published
     unsigned* ticket;           // [B], zero at launch: workgroups of a frame take their row group in arrival order
     int* status;                // pinned host word: set to 1 when a poll gave up (the maps are then wrong)
+    unsigned long long* trace;  // diagnostics (SGM_UPSUM_TRACE): [B][ngroups][4] 100 MHz timestamps: ticket drawn, first hand-over seen, last step done, xcc/cu id
     unsigned gen;
     int W, H, D, dmin, B, p1, ngroups;
     int check_unique;
@@ -120,7 +121,7 @@ static __device__ __forceinline__ void store_cells_sc1(uint8_t* p, const CellVec
 // planes summed whole by this kernel (reference order ref :213-220: 0 (1,0), 1 (-1,0), 2 (0,1), 4 (1,1), 7 (-1,1)); 3 = (0,-1),
 // 5 = (-1,-1) and 6 = (1,-1) are the sweep computed here (5 and 6 are read in their post-wrap triangles only)
 template <int DPL, int R, bool PAD, bool FAST>
-__global__ __launch_bounds__(R * 256) void sgm_upsum_k(const UpArgs a)
+__global__ __launch_bounds__(R * 256 + 64) void sgm_upsum_k(const UpArgs a)
 {
     constexpr int Dp = 16 * DPL;
     constexpr int LD = Dp + 2;
@@ -142,10 +143,66 @@ __global__ __launch_bounds__(R * 256) void sgm_upsum_k(const UpArgs a)
 
     const int W = a.W, H = a.H, D = a.D, dmin = a.dmin;
     const int frame = blockIdx.x % a.B;
-    if (threadIdx.x == 0) group_s = atomicAdd(&a.ticket[frame], 1u);
     if (threadIdx.x < 256) lut32_s[threadIdx.x] = (unsigned)a.lut[threadIdx.x] * 0x00010001u;
+    // A frame's row groups are taken in arrival order by the few workgroups the launch has per frame (a.ngroups of them would mostly
+    // sit waiting for the rows below while holding a CU's LDS): whoever finishes a group takes the next one.  A group only ever
+    // waits for the group before it, whose ticket was drawn earlier -- by a workgroup that is running or done.
+    // The last wave of the workgroup computes nothing: it polls the progress word of the group below and publishes this group's.
+    // Vector-memory results return in issue order, so a poll in a computing wave would drain that wave's plane prefetch every step.
+    const bool helper = threadIdx.x >= R * 256;
+    unsigned* const prog = a.progress + (size_t)frame * a.ngroups;
+    const unsigned gen_base = a.gen << 13;
+    const int x_last = a.do_right ? W - 1 + dmin + D - 1 : W - 1;        // last column any pixel of a row needs
+    const int n_steps = (x_last + R - 1) / 16 + 1 + (R - 1);             // team t runs iteration step - t (clamped work outside its range)
+    int k_prev = -1;
+    for (;;) {
+    __syncthreads();                                                     // the previous group's ring / extras / ticket word are done with, its stores drained
+    if (helper && k_prev >= 0)                                           // ... so all of its top team's iterations are out
+        __hip_atomic_store(&prog[k_prev], gen_base + (unsigned)(n_steps - R + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) group_s = atomicAdd(&a.ticket[frame], 1u);
     __syncthreads();
     const int k = (int)group_s;                                          // row group, counted from the bottom of the image
+    if (k >= a.ngroups) break;
+    k_prev = k;
+    unsigned long long* const tr = a.trace ? a.trace + ((size_t)frame * a.ngroups + k) * 4 : nullptr;
+    if (helper) {
+        if (tr && threadIdx.x == R * 256) {
+            tr[0] = __builtin_amdgcn_s_memrealtime();
+            unsigned xcc, hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            tr[3] = ((unsigned long long)(xcc & 0xF) << 32) | hw;
+        }
+        // the group below must have published every column < W up to `col` (its top team's windows are shifted R - 1 columns)
+        bool gave_up = false;
+        auto wait_for = [&](int col) {
+            if (gave_up || k == 0) return;                               // one timed-out poll: finish the launch without waiting again
+            const unsigned want = gen_base + (unsigned)((min(col, W - 1) + R - 1) / 16 + 1);
+            unsigned polls = 0;
+            while ((int)(__hip_atomic_load(&prog[k - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++polls > UPSUM_POLL_LIMIT) {                        // never in a healthy launch; do not hang the GPU
+                    if (a.status) *a.status = 1;
+                    gave_up = true;
+                    break;
+                }
+            }
+        };
+        wait_for(16);                                                    // iteration 0 of the bottom team reads columns -1 .. 16
+        if (tr && threadIdx.x == R * 256) tr[1] = __builtin_amdgcn_s_memrealtime();
+        __syncthreads();
+        for (int step = 0; step < n_steps; ++step) {
+            wait_for(16 * (step + 1) + 16);                              // what the bottom team prefetches behind barrier A: columns of iteration step + 1
+            __syncthreads();                                             // A
+            // The top team's hand-over stores of step - 1 were issued before that step's barrier A and its census loads behind it;
+            // every wave of the team has consumed those loads by now, and vector-memory operations complete in issue order
+            if (step - R + 1 >= 1)
+                __hip_atomic_store(&prog[k], gen_base + (unsigned)(step - R + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();                                             // B
+        }
+        if (tr && threadIdx.x == R * 256) tr[2] = __builtin_amdgcn_s_memrealtime();
+        continue;
+    }
     const int t = threadIdx.x >> 8;                                      // team: 0 = the group's bottom row
     const int tid = threadIdx.x & 255;
     const int sub = tid & 15, px = tid >> 4;
@@ -162,8 +219,6 @@ __global__ __launch_bounds__(R * 256) void sgm_upsum_k(const UpArgs a)
     float* const disp_r = a.disp_r + (size_t)frame * W * H + (size_t)yc * W;
     uint8_t* const xb_out = a.xbuf + ((size_t)frame * 2 + (size_t)(k & 1)) * 3 * (size_t)W * Dp;
     const uint8_t* const xb_in = a.xbuf + ((size_t)frame * 2 + (size_t)((k + 1) & 1)) * 3 * (size_t)W * Dp;
-    unsigned* const prog = a.progress + (size_t)frame * a.ngroups;
-    const unsigned gen_base = a.gen << 13;
 
     // ---- second visits of the anomalous lines that land on this team's row (as in sgm_sum_wta_lr_k) ----
     const int n_extra = row_ok ? min(a.row_extra_count[yc], UPSUM_MAX_EXTRA) : 0;
@@ -201,8 +256,6 @@ __global__ __launch_bounds__(R * 256) void sgm_upsum_k(const UpArgs a)
     const uint8_t* const pd_ul = planes + 5 * a.plane_bytes;             // (-1,-1)
     const uint8_t* const pd_ur = planes + 6 * a.plane_bytes;             // (1,-1)
 
-    const int x_last = a.do_right ? W - 1 + dmin + D - 1 : W - 1;        // last column any pixel of the row needs
-    const int n_steps = (x_last + R - 1) / COLS + 1 + (R - 1);           // team t runs iteration step - t (clamped work outside its range)
 
     // column of this thread in iteration i: 16 i - t + px (team t is shifted t columns to the left of the bottom team, so the
     // cells x-1 .. x+1 of the row below are always at least one iteration old)
@@ -241,30 +294,15 @@ __global__ __launch_bounds__(R * 256) void sgm_upsum_k(const UpArgs a)
         load_cells_sc1<DPL>(xb_in + dirb + (size_t)c1 * Dp + lane_off, hin[1]);
         load_cells_sc1<DPL>(xb_in + 2 * dirb + (size_t)c2 * Dp + lane_off, hin[2]);
     };
-    // the group below must have published every column < W up to `col` (its top team's windows are shifted R - 1 columns)
-    bool gave_up = false;
-    auto wait_for = [&](int col) {
-        if (gave_up) return;                                             // one timed-out poll: finish the launch without waiting again
-        const unsigned want = gen_base + (unsigned)((min(col, W - 1) + R - 1) / COLS + 1);
-        unsigned polls = 0;
-        while ((int)(__hip_atomic_load(&prog[k - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++polls > UPSUM_POLL_LIMIT) {                            // never in a healthy launch; do not hang the GPU
-                if (a.status) *a.status = 1;
-                gave_up = true;
-                break;
-            }
-        }
-    };
     const bool from_global = (t == 0 && k > 0);
 
-    if (from_global && tid < 64) wait_for(COLS);                         // iteration 0 of this team reads columns -1 .. 16
-    __syncthreads();                                                     // ... and ex_val / ex_col are in place
+    __syncthreads();                                                     // ex_val / ex_col are in place, the helper has seen iteration 0's columns
+    // issue order = the order of use: a load's data waits for every older load (vmcnt counts in issue order)
     fetch_planes(0, col_of(-t));
-    fetch_planes(1, col_of(1 - t));
     fetch_row(col_of(-t));
     if (from_global) fetch_handover(col_of(-t));
-    else { hin[0].w[0] = hin[1].w[0] = hin[2].w[0] = 0; if (NW > 1) { hin[0].w[NW - 1] = hin[1].w[NW - 1] = hin[2].w[NW - 1] = 0; } }
+    fetch_planes(1, col_of(1 - t));
+    if (!from_global) { hin[0].w[0] = hin[1].w[0] = hin[2].w[0] = 0; if (NW > 1) { hin[0].w[NW - 1] = hin[1].w[NW - 1] = hin[2].w[NW - 1] = 0; } }
 
     int slot = px;                                                       // ring slot of this thread's column (advances 16 per step)
     unsigned sent[2] = {0x00FF00FFu, 0x00FF00FFu};
@@ -275,9 +313,31 @@ __global__ __launch_bounds__(R * 256) void sgm_upsum_k(const UpArgs a)
         const int x = col_of(i);
         const int xc = min(max(x, 0), W - 1);
         const bool inside = row_ok && x >= 0 && x < W;
-        // ---- the poll for what this step's prefetch of the hand-over will read (bottom team, one wave) ----
-        if (from_global && tid < 64) wait_for(COLS * (i + 1) + COLS);        // ... columns 16 (i+1) - 1 .. 16 (i+1) + 16
-
+        // ---- S = five planes + the sweep (+ anomalous visits): packed u16 pairs as in sgm_sum_wta_lr_k ----
+        unsigned aL[NW], aH[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) aL[w] = aH[w] = 0;
+        auto add_bytes = [&](int w, unsigned v) {
+            aL[w] += v & 0x00FF00FFu;                                        // bytes 0, 2
+            aH[w] += __builtin_amdgcn_perm(0u, v, 0x0c030c01u);              // bytes 1, 3
+        };
+#pragma unroll
+        for (int d = 0; d < 5; ++d)
+#pragma unroll
+            for (int w = 0; w < NW; ++w) add_bytes(w, pre[STAGE][d].w[w]);
+        const bool in_ul = xc >= tri_r, in_ur = xc < tri_l;                  // post-wrap cells: the aggregation launch computed them
+        const unsigned m_pl_ul = in_ul ? 0xFFFFFFFFu : 0u, m_pl_ur = in_ur ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            add_bytes(w, pre_ul[STAGE].w[w] & m_pl_ul);
+            add_bytes(w, pre_ur[STAGE].w[w] & m_pl_ur);
+        }
+        for (int j = 0; j < n_extra; ++j) {
+            if (ex_col[t][j] == x) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) add_bytes(w, ex_val[t][j * (Dp / 4) + sub * NW + w]);
+            }
+        }
         // ---- the three directions of the sweep ----
         us2 C[NP];
         const int lim = xc - lim_bias;
@@ -352,31 +412,6 @@ __global__ __launch_bounds__(R * 256) void sgm_upsum_k(const UpArgs a)
                 store_cells_sc1<DPL>(o + 2 * dirb, o2);
             }
         }
-        // ---- S = five planes + the sweep (+ anomalous visits): packed u16 pairs as in sgm_sum_wta_lr_k ----
-        unsigned aL[NW], aH[NW];
-#pragma unroll
-        for (int w = 0; w < NW; ++w) aL[w] = aH[w] = 0;
-        auto add_bytes = [&](int w, unsigned v) {
-            aL[w] += v & 0x00FF00FFu;                                        // bytes 0, 2
-            aH[w] += __builtin_amdgcn_perm(0u, v, 0x0c030c01u);              // bytes 1, 3
-        };
-#pragma unroll
-        for (int d = 0; d < 5; ++d)
-#pragma unroll
-            for (int w = 0; w < NW; ++w) add_bytes(w, pre[STAGE][d].w[w]);
-        const bool in_ul = xc >= tri_r, in_ur = xc < tri_l;                  // post-wrap cells: the aggregation launch computed them
-        const unsigned m_pl_ul = in_ul ? 0xFFFFFFFFu : 0u, m_pl_ur = in_ur ? 0xFFFFFFFFu : 0u;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            add_bytes(w, pre_ul[STAGE].w[w] & m_pl_ul);
-            add_bytes(w, pre_ur[STAGE].w[w] & m_pl_ur);
-        }
-        for (int j = 0; j < n_extra; ++j) {
-            if (ex_col[t][j] == x) {
-#pragma unroll
-                for (int w = 0; w < NW; ++w) add_bytes(w, ex_val[t][j * (Dp / 4) + sub * NW + w]);
-            }
-        }
         // own cells of the two diagonals: everything that is neither post-wrap nor the anomalous line's empty track
         const unsigned m_own_ul = (in_ul || xc == tri_r - 1) ? 0u : 0xFFFFFFFFu;
         const unsigned m_own_ur = (in_ur || xc == tri_l) ? 0u : 0xFFFFFFFFu;
@@ -418,11 +453,11 @@ __global__ __launch_bounds__(R * 256) void sgm_upsum_k(const UpArgs a)
         }
         const unsigned ksecond_l = row_allmin<16>(k2) + kbest_l + 1;
 
-        __syncthreads();                                                 // A: ring columns, exchange cells and the poll are done
-        // ---- prefetch: planes of this team's iteration two steps ahead, census / grey / hand-over cells of the next ----
-        fetch_planes(STAGE, col_of(i + 2));
+        __syncthreads();                                                 // A: ring columns, exchange cells and the helper's poll are done
+        // ---- prefetch, in the order of use: census / grey / hand-over cells of the next iteration, then the planes of the one after ----
         fetch_row(col_of(i + 1));
         if (from_global) fetch_handover(col_of(i + 1));
+        fetch_planes(STAGE, col_of(i + 2));
 
         // ---- right view from the ring, then ONE wta_finish for both views (lane 0: left, lane 1: right) ----
         unsigned kbest_r = 0, ksecond_r = 0;
@@ -474,12 +509,7 @@ __global__ __launch_bounds__(R * 256) void sgm_upsum_k(const UpArgs a)
                 *out = wta_finish(st, D, dmin, a.check_unique, a.one_minus_ratio);
             }
         }
-        // the top team's hand-over stores were issued before barrier A; at least seven vector loads (fetch_planes) are younger:
-        // once at most six operations are outstanding the stores have reached L2 (vmcnt counts in issue order)
-        if (t == R - 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __syncthreads();                                                 // B: every diagonal of this step has been read (TIGHT ring)
-        if (t == R - 1 && tid == 0 && i >= 0)
-            __hip_atomic_store(&prog[k], gen_base + (unsigned)(i + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         slot += COLS;
         if (slot >= RC) slot -= RC;
     };
@@ -490,12 +520,14 @@ __global__ __launch_bounds__(R * 256) void sgm_upsum_k(const UpArgs a)
         body(step + 1, std::integral_constant<int, 1>{});
     }
     if (step < n_steps) body(step, std::integral_constant<int, 0>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // this wave's hand-over stores are out before the group is called done
+    }
 }
 
 template <int DPL, int R>
-static void launch_upsum(const UpArgs& a, bool pad, bool fast, hipStream_t st)
+static void launch_upsum(const UpArgs& a, bool pad, bool fast, int wgs_per_frame, hipStream_t st)
 {
-    const dim3 grid((unsigned)(a.ngroups * a.B)), block(R * 256);
+    const dim3 grid((unsigned)(wgs_per_frame * a.B)), block(R * 256 + 64);
     if (pad) {
         if (fast) hipLaunchKernelGGL((sgm_upsum_k<DPL, R, true, true>), grid, block, 0, st, a);
         else      hipLaunchKernelGGL((sgm_upsum_k<DPL, R, true, false>), grid, block, 0, st, a);
@@ -556,14 +588,46 @@ int sgmd_upsum(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* path
     a.one_minus_ratio = one_minus_ratio;
     a.do_right = do_right;
     HIP_TRY(hipMemsetAsync(a.ticket, 0, (size_t)g->B * sizeof(unsigned), st));
+    // diagnostics: SGM_UPSUM_TRACE=file -> per-group timestamps of THIS launch are written there (the launch is waited for)
+    static const char* trace_path = getenv("SGM_UPSUM_TRACE");
+    static unsigned long long* d_trace = nullptr;
+    static size_t trace_cap = 0;
+    const size_t trace_n = (size_t)g->B * a.ngroups * 4;
+    a.trace = nullptr;
+    if (trace_path && *trace_path) {
+        if (trace_n > trace_cap) {
+            if (d_trace) (void)hipFree(d_trace);
+            HIP_TRY(hipMalloc((void**)&d_trace, trace_n * 8));
+            trace_cap = trace_n;
+        }
+        HIP_TRY(hipMemsetAsync(d_trace, 0, trace_n * 8, st));
+        a.trace = d_trace;
+    }
     const bool pad = g->D != g->Dp;
     const bool fast = paths->allow_fast && paths->p1 <= 31488 && paths->pen_max <= 223;
+    // workgroups per frame: what the chain of row groups can keep busy at once (steps of a group / steps between the starts of two
+    // groups), not one per group -- the others would hold LDS waiting
+    static const int env_wgs = getenv("SGM_UPSUM_WGS") ? atoi(getenv("SGM_UPSUM_WGS")) : 0;
+    int wgs = env_wgs > 0 ? env_wgs : (R == 1 ? 48 : 24);
+    if (wgs > a.ngroups) wgs = a.ngroups;
     switch (R) {
-    case 1: launch_upsum<8, 1>(a, pad, fast, st); break;
-    case 2: launch_upsum<8, 2>(a, pad, fast, st); break;
-    default: launch_upsum<8, 3>(a, pad, fast, st); break;
+    case 1: launch_upsum<8, 1>(a, pad, fast, wgs, st); break;
+    case 2: launch_upsum<8, 2>(a, pad, fast, wgs, st); break;
+    default: launch_upsum<8, 3>(a, pad, fast, wgs, st); break;
     }
     HIP_TRY(hipGetLastError());
+    if (a.trace) {
+        unsigned long long* h = (unsigned long long*)malloc(trace_n * 8);
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(h, d_trace, trace_n * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(trace_path, "wb")) {
+            const int hdr[4] = {g->B, a.ngroups, R, 0};
+            fwrite(hdr, sizeof hdr, 1, f);
+            fwrite(h, 8, trace_n, f);
+            fclose(f);
+        }
+        free(h);
+    }
     return 0;
 }
 
