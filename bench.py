@@ -1071,7 +1071,7 @@ def main():
     args = ap.parse_args()
     if args.mode == "tiles":
         # a rank of the tile pipeline keeps ~N + 3 HIP streams busy, some with millisecond-long serial kernels (tile_begin's
-        # horizontal lines); on HIP's default of 4 hardware queues short kernels queue up behind those (measured, DESIGN.md
+        # horizontal lines); on HIP's default of 4 hardware queues short kernels queue up behind those (measured, NOTES.md
         # section 7: 1.9 -> 1.45 ms per frame for one rank of eight at 3840x2160).  Read by the runtime when it starts.
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
         import soc_project_stereo_matching_amd.tile_bench as tb

@@ -5,7 +5,7 @@
  * The reference has no multi-GPU code at all ("no NCCL/MPI call site"); its intended call site for the
  * matcher is C -- ZedBoard/Vitis/lwip_tcp_perf_client/src/stereo_matching.c:34-40, start_stereo_matching() -- and this is
  * what such a caller uses to spread a frame over more than one MI355X.  What is split, and why it is a pipeline and not a
- * halo stencil, is described with the sgm_tile_* entry points in sgm_mi355x.h (row tiles) and in DESIGN.md section 7:
+ * halo stencil, is described with the sgm_tile_* entry points in sgm_mi355x.h (row tiles) and in DESIGN.md section 6:
  * rank r computes rows [r0, r1) of every frame; the vertical and diagonal paths (SemiGlobalMatching.c:229-372, six of the
  * eight directions of .c:213-220) cross the tile borders, so each of the two vertical sweeps hands one image row of path
  * costs per direction from rank to rank, and with several frames in flight the ranks work as a systolic pipeline.
@@ -66,7 +66,7 @@ int  sgm_tile_slots_needed(int world, int lead);
 /* Device memory one slot of a rank that owns rows [row_begin, row_end) takes: per frame of its batch the 8 direction planes of the tile's rows + one hand-over row
  * either side (1 B per cell of the padded disparity range), ~64 B per pixel of the WHOLE frame (maps, census, labels, median
  * scratch, the row-gather buffer) and 4 hand-over buffers.  A rank holds sgm_tile_slots_needed(world, lead) [+ spare - 1] of them:
- * sgm_tiles_create and tiling.DeviceSlotEngine refuse a configuration that does not fit (DESIGN.md section 7 has the table).
+ * sgm_tiles_create and tiling.DeviceSlotEngine refuse a configuration that does not fit (DESIGN.md section 6 has the table).
  * 0 for an empty or out-of-frame row range. */
 size_t sgm_tile_slot_bytes(int row_begin, int row_end, uint16_t width, uint16_t height, const SGMOption* option, int batch);
 /* steps a stream of n_frames takes until its last result is queued */
@@ -128,7 +128,7 @@ typedef void (*sgm_tiles_result_fn)(void* user, long frame, const float* d_map, 
 
 /* width x height frames (`batch` of them per step: every call covers the same tile of `batch` frames, images and maps
  * [batch][H][W]), options as for SGM_Initialize; lead = steps tile_begin is queued ahead of the frame's first sweep (2 is a good
- * value, DESIGN.md section 7); spare >= 1 = slots beyond the schedule's need (how long a result stays readable);
+ * value, DESIGN.md section 6); spare >= 1 = slots beyond the schedule's need (how long a result stays readable);
  * throttle = how many steps the host may run ahead of the GPU (0: unbounded).  The transport is used, not owned. */
 sgm_tiles* sgm_tiles_create(int device, int rank, int world, uint16_t width, uint16_t height, const SGMOption* option, int batch,
                             int lead, int spare, int throttle, const sgm_tiles_transport* transport);

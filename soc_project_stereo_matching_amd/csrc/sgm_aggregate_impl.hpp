@@ -2,7 +2,7 @@
 #include "sgm_common.hpp"
 
 #ifndef SGM_AGG_PF
-#define SGM_AGG_PF 2      // steps of census words / grey values a wave keeps in flight (8- and 16-lane lines); 3 measured no faster
+#define SGM_AGG_PF 2      // steps of census words / grey values a wave keeps in flight (8- and 16-lane lines); 3 measured no faster (NOTES.md 9)
 #endif
 #ifndef SGM_ANOM_PF
 #define SGM_ANOM_PF 4     // ... and for the anomalous diagonal lines (a kernel of their own: registers are no concern there)
@@ -312,7 +312,9 @@ enum { AGG_H = 0, AGG_V = 1, AGG_D = 2 };
 // instructions per step instead of the ~17 of the reference's two-tracker state machine (which W <= H still needs:
 // there the off-by-one tracker makes lines wrap early).
 // VOL: the matching cost comes from a materialised volume (wide census windows) instead of the census images.
-template <int DPL, bool PAD, int LPP, int KIND, int NN, bool WIDE = false, bool VOL = false>
+// PWO (diagonal lines of W > H only): store only the cells BEHIND the line's wrap around the image edge -- what the fused last sweep
+// (sgm_upsum.hip) cannot compute itself; a separate instantiation, so the ordinary lines pay nothing for it.
+template <int DPL, bool PAD, int LPP, int KIND, int NN, bool WIDE = false, bool VOL = false, bool PWO = false>
 static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFrame& fr, const unsigned short* lut_s,
                                                    const unsigned* lut32_s, int dir, int grp)
 {
@@ -331,7 +333,7 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
     const int skip = (KIND == AGG_H) ? 0 : (fwd ? a.row_begin : H - a.row_end);    // rows between that edge and the tile
     const bool import_state = skip > 0;
     const int nlines = (KIND == AGG_H) ? rows : a.line_lo[dir] + a.line_n[dir];   // ref :238 (W lines; a subset for the fused last sweep)
-    const bool pwo = (KIND == AGG_D) && ((a.post_wrap_mask >> dir) & 1);   // store only behind the line's wrap
+    constexpr bool pwo = PWO;
     bool wrapped = false;
     const int nsteps = (KIND == AGG_H) ? W - 1 : (import_state ? rows : rows - 1);   // ref :281
     if (KIND == AGG_D && W < 2) return;                                    // the only line is the anomalous one
@@ -400,7 +402,7 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
             off += (unsigned)dstep_off;
         } else if (WIDE) {
             const bool wrap = (pcol == wrap_at);
-            wrapped = wrapped || wrap;
+            if constexpr (PWO) wrapped = wrapped || wrap;
             pcol = wrap ? wrap_to : pcol + (unsigned)col_step;
             p += wrap ? pstep_w : pstep_n;
             off += wrap ? ostep_w : ostep_n;
@@ -499,7 +501,7 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
         if (1 + u <= nsteps) {
             advance();
             ob[u] = off;
-            wb[u] = wrapped;
+            if constexpr (PWO) wb[u] = wrapped;
             limb[u] = x - lim_bias;
             fetch(cb[u], clb[u], gb[u]);
         }
@@ -522,7 +524,7 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
             if (refill) {                                                      // the slot's census words are consumed now
                 advance();
                 ob[u] = off;
-                wb[u] = wrapped;
+                if constexpr (PWO) wb[u] = wrapped;
                 limb[u] = x - lim_bias;
                 fetch(cb[u], clb[u], gb[u]);
             }
@@ -533,7 +535,7 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
             if (refill) {
                 advance();
                 ob[u] = off;
-                wb[u] = wrapped;
+                if constexpr (PWO) wb[u] = wrapped;
                 limb[u] = x - lim_bias;
                 fetch(cb[u], clb[u], gb[u]);
             }
@@ -887,7 +889,15 @@ __global__ __launch_bounds__(64) void sgm_aggregate_k(const AggArgs a)
         else               agg_regular<DPL, PAD, LPP, AGG_H, NN, false, VOL>(a, fr, lut_s, lut32_s, dir, grp);
     }
     else if (a.dx[dir] == 0) agg_regular<DPL, PAD, LPP, AGG_V, NN, false, VOL>(a, fr, lut_s, lut32_s, dir, grp);
-    else if (a.W > a.H)      agg_regular<DPL, PAD, LPP, AGG_D, NN, true, VOL>(a, fr, lut_s, lut32_s, dir, grp);
+    else if (a.W > a.H) {
+        if constexpr (NN != 0 && !VOL) {                                      // the fused last sweep exists for the non-negative-P1 census path only
+            if ((a.post_wrap_mask >> dir) & 1) {
+                agg_regular<DPL, PAD, LPP, AGG_D, NN, true, VOL, true>(a, fr, lut_s, lut32_s, dir, grp);
+                return;
+            }
+        }
+        agg_regular<DPL, PAD, LPP, AGG_D, NN, true, VOL>(a, fr, lut_s, lut32_s, dir, grp);
+    }
     else                     agg_regular<DPL, PAD, LPP, AGG_D, NN, false, VOL>(a, fr, lut_s, lut32_s, dir, grp);
 }
 

@@ -3,7 +3,7 @@
  * operation a rank performs in which step, as calls on an engine vtable.  The device pipeline (sgm_tiles.c) and tiling.py's
  * TilePipeline (Python engines, the CPU tests over gloo) both run exactly this function.
  *
- * Why the schedule looks like this (DESIGN.md section 7): six of the eight path directions of the reference
+ * Why the schedule looks like this (DESIGN.md section 6): six of the eight path directions of the reference
  * (SemiGlobalMatching.c:213-220; the recurrence of .c:229-372) are recurrences along y, so tile k cannot start its downward
  * directions before tile k-1 has handed over the path costs of its last row, and the upward ones flow the other way.  With
  * frames in flight the hand-overs form a systolic pipeline over the ranks.

@@ -128,7 +128,7 @@ static int eng_exchange(void* u, const sgm_tile_xop* ops, int n_ops, const int* 
             /* rows [row_begin, row_end) of every map of the slot.  One frame per step: they are contiguous in the map.  A batch: the
              * same rows of its B maps travel as ONE message per peer -- packed into / unpacked from the slot's d_pack by one strided
              * device copy on the communication stream (per step world - 1 messages on the owner instead of (world - 1) * B; the
-             * exchange is latency-bound, DESIGN.md section 7) */
+             * exchange is latency-bound, DESIGN.md section 6) */
             const size_t rows = (size_t)(o->row_end - o->row_begin), row_bytes = (size_t)t->W * sizeof(float);
             char* const in_map = (char*)s->d_map + (size_t)o->row_begin * row_bytes;
             if (t->batch == 1) {

@@ -238,7 +238,7 @@ def match_tiled_in_process(engines, left, right):
 # Every rank issues the same step sequence, so each send meets its receive in the same exchange.  The exchange is queued
 # before the step's tile_finish: the next step's sweeps wait for it, and it waits for whatever its slots have queued so
 # far, so a cost sum queued in front of it would sit on the chain sweep -> exchange -> sweep that paces the pipeline
-# (DESIGN.md section 7).  A frame lives in one of R
+# (DESIGN.md section 6).  A frame lives in one of R
 # >= N+3 slots per rank (a slot = an SGMInstance restricted to the rank's rows, its stream, its hand-over buffers and a
 # [H][W] disparity map); nothing blocks the host: kernels of a slot are ordered by its stream, exchanges run on a
 # communication stream, and HIP events order the two (slot -> exchange -> slot).  In the steady state every rank does

@@ -74,10 +74,16 @@ def test_defaults_are_the_driver_contract():
 
 
 def test_committed_bench_line_has_the_contract_keys():
-    """profiles/r03_bench.json is a line the driver's command printed on an MI355X for the committed kernels: the keys the contract
-    names, both extra objects, every single-GPU BASELINE workload verified, nothing mismatched."""
-    with open(os.path.join(ROOT, "profiles", "r03_bench.json")) as f:
+    """profiles/r04_bench_detail.json is the full object behind the line the driver's command printed on an MI355X for the committed
+    kernels (bench_detail.json of that run): the keys the contract names, both extra objects, every single-GPU BASELINE workload
+    verified, nothing mismatched; profiles/r04_bench.json is the compact line itself as stdout carried it."""
+    with open(os.path.join(ROOT, "profiles", "r04_bench_detail.json")) as f:
         d = json.load(f)
+    with open(os.path.join(ROOT, "profiles", "r04_bench.json")) as f:
+        raw = f.read()
+    assert raw.count("\n") <= 1 and len(raw) < bench.COMPACT_LIMIT
+    line = json.loads(raw)
+    assert line == bench.compact_line(d) and line["value"] == d["value"] and line["roofline"]["frac"] == d["roofline"]["frac"]
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k

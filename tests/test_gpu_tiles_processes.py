@@ -31,11 +31,29 @@ def rank_exe(tmp_path_factory):
     (1242, 375, 128, 4, 1, 2, 6),                  # KITTI size in 4 tiles
 ], ids=lambda c: f"{c[0]}x{c[1]}_d{c[2]}_n{c[3]}_b{c[4]}_lead{c[5]}")
 def test_c_pipeline_ranks_as_processes(oracle, rank_exe, tmp_path, case):
+    _run_ranks(oracle, rank_exe, tmp_path, case, None)
+
+
+@pytest.mark.parametrize("case", [(300, 70, 48, 2, 2, 2, 5), (1242, 375, 128, 4, 8, 2, 6)],
+                         ids=lambda c: f"{c[0]}x{c[1]}_d{c[2]}_n{c[3]}_b{c[4]}_lead{c[5]}")
+def test_c_pipeline_over_rccl_between_gpus(oracle, rank_exe, tmp_path, case):
+    """The same ranks on a GPU EACH, connected by the library's RCCL transport (grouped ncclSend / ncclRecv over xGMI): the run this
+    pool's one-GPU boxes cannot make -- skipped unless the box has a GPU per rank.  Ready for the first multi-GPU node."""
+    import torch
+    if torch.cuda.device_count() < case[3]:
+        pytest.skip(f"needs {case[3]} GPUs (RCCL refuses two ranks on one device); this box has {torch.cuda.device_count()}")
+    _run_ranks(oracle, rank_exe, tmp_path, case, "rccl")
+
+
+def _run_ranks(oracle, rank_exe, tmp_path, case, transport):
     from oracle.pyoracle import default_option
     w, h, d, world, batch, lead, steps = case
     seed = 0x7A110 + w
+    env = dict(os.environ)
+    if transport:
+        env["SGM_TILES_TRANSPORT"] = transport
     procs = [subprocess.Popen([rank_exe, str(tmp_path), str(r), str(world), str(w), str(h), str(d), str(batch), str(lead), str(steps),
-                               str(seed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+                               str(seed)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
     outs = []
     try:
         for p in procs:

@@ -1,6 +1,6 @@
 """The C host of the multi-GPU row-tile path (include/sgm_tiles.h; csrc/sgm_tile_sched.c, csrc/sgm_tiles.c) on the CPU.
 
-* the step schedule (sgm_tile_step) against an independent Python restatement of DESIGN.md section 7's step order, call by
+* the step schedule (sgm_tile_step) against an independent Python restatement of DESIGN.md section 6's step order, call by
   call, for 1..8 ranks, leads 0..3 and streams shorter and longer than the pipeline;
 * the device pipeline (sgm_tiles_*) END TO END with ranks as threads: csrc/sgm_host.c + sgm_tiles.c + sgm_tile_sched.c linked
   with tests/stub_device.c in its toy-compute mode (a recurrence with the data dependencies of SGM's vertical / diagonal paths,
@@ -23,7 +23,7 @@ INC = os.path.join(ROOT, "include")
 
 # ------------------------------------------------------------------------------------------ the schedule, restated
 def restated_trace(rank, world, height, slots, lead, n_frames, rows_of):
-    """DESIGN.md section 7's step order written down again in Python (test infrastructure): the calls one rank makes."""
+    """DESIGN.md section 6's step order written down again in Python (test infrastructure): the calls one rank makes."""
     r, N, F, K, R = rank, world, n_frames, lead, slots
     slot = lambda f: f % R                                           # noqa: E731
     valid = lambda f: 0 <= f < F                                     # noqa: E731
@@ -402,7 +402,7 @@ def test_slot_memory_estimate_and_the_guard_of_create(stub, capfd):
     assert planes == 34005319680 and planes < per_slot < planes * 1.15             # + ~64 B per pixel of the frame
     assert tiles.slot_bytes(0, h, w, h, opt, 1) == 8 * h * w * 128 + 64 * w * h + 12 * w * 128      # one rank: no hand-over rows
     assert tiles.slot_bytes(5, 5, w, h, opt, 1) == 0 and tiles.slot_bytes(0, h + 1, w, h, opt, 1) == 0
-    # DESIGN.md section 7's table: GB per GPU for N = 1, 2, 4, 8 at a lead of 2
+    # DESIGN.md section 6's table: GB per GPU for N = 1, 2, 4, 8 at a lead of 2
     gb = {n: [tiles.slot_bytes(*tiles.tile_rows(h, n, 0), w, h, opt, b) * tiles.slots_needed(n, 2) / 1e9 for b in (1, 4, 8)] for n in (1, 2, 4, 8)}
     assert [round(v) for v in gb[2]] == [34, 134, 268] and [round(v) for v in gb[8]] == [21, 84, 167]
     # the stub device reports 200 GiB free: 2 ranks x batch 8 is refused with a message, batch 4 is accepted

@@ -191,14 +191,27 @@ def main():
                   uniqueness_ratio=float(rng.choice([0.99, 0.95, 0.8])), lrcheck_thres=float(rng.choice([1.0, 0.0, 2.5])))
         opt = default_option(dmin + d, dmin, **kw)
         seed = int(rng.integers(1, 2**31))
-        modes = os.environ.get("FUZZ_MODES", "plain,plain,batch,batch,separate,window,rightview,tiles,planes,pipe,cpipe").split(",")
+        modes = os.environ.get("FUZZ_MODES", "plain,plain,batch,batch,separate,window,rightview,tiles,planes,pipe,cpipe,upsum").split(",")
         mode = str(rng.choice(modes))
+        if mode == "upsum":
+            # the fused last sweep (SGM_UPSUM=1, csrc/sgm_upsum.hip): it needs W > H and a padded range of 128 -- make most draws qualify
+            # (the others, and negative P1, fall back to the separate kernels inside the library: still a valid case)
+            if rng.random() < 0.85:
+                d = int(rng.choice([128, 128, 100, 117, 70, 65]))
+                w = max(w, 64)
+                h = int(min(h, w - 1, rng.integers(4, 200)))
+                opt = default_option(dmin + d, dmin, **kw)
+            if w * h * d > 40e6:
+                continue
         if mode == "tiles" and h < 4:
             mode = "plain"
-        B = int(rng.integers(2, 5)) if mode == "batch" else 1
+        B = int(rng.integers(2, 5)) if mode == "batch" else (int(rng.integers(1, 4)) if mode == "upsum" else 1)
         frames = [orc.synth_pair(w, h, d, seed + k) for k in range(B)]
         if mode == "separate":
             os.environ["SGM_FUSED_WTA"] = "0"
+        if mode == "upsum":                                   # read when the instance is created
+            os.environ["SGM_UPSUM"] = "1"
+            os.environ["SGM_UPSUM_ROWS"] = str(int(rng.integers(1, 4)))
         win = (5, 5)
         if mode == "window":
             win = [(7, 7), (9, 7), (3, 5), (7, 9), (1, 1), (63, 1)][int(rng.integers(0, 6))]
@@ -224,7 +237,7 @@ def main():
         inst = S.SGMInstance(0, batch=B)
         inst.set_census_window(*win)
         inst.set_reference_view(mode == "rightview")
-        keep = bool(rng.random() < 0.5)
+        keep = bool(rng.random() < (0.15 if mode == "upsum" else 0.5))
         inst.keep_stages(keep)
         if rng.random() < 0.5:
             inst.set_overlap_post(True)                   # post pass on the instance's second stream
@@ -248,16 +261,25 @@ def main():
                     if not same(inst.read_stage(name), wants[k][name]):
                         diffs.append(f"frame {k} {name}")
             n += 1
+            if mode == "upsum":
+                n_up = globals().get("_n_up", [0, 0])
+                n_up[0] += 1
+                n_up[1] += 1 if inst.fused_sweep_rows() else 0
+                globals()["_n_up"] = n_up
             if diffs:
                 bad += 1
                 print(f"MISMATCH {w}x{h} d=[{dmin},{dmin + d}) mode={mode} B={B} win={win} keep={keep} seed={seed} opts={kw}: {diffs[:6]}", flush=True)
         finally:
             inst.close()
             os.environ.pop("SGM_FUSED_WTA", None)
+            for k_ in ("SGM_UPSUM", "SGM_UPSUM_ROWS"):                   # (SGM_UPSUM_WGS is read once per process: set it outside)
+                os.environ.pop(k_, None)
             orc.set_census_window(5, 5)
             orc.set_reference_view(False)
         if n % 20 == 0:
             print(f"{n} cases, {bad} mismatching, {time.time() - t0:.0f} s", flush=True)
+    if "_n_up" in globals():
+        print(f"upsum mode: {_n_up[0]} cases, {_n_up[1]} of them ran the fused last sweep")
     print(f"done: {n} cases, {bad} mismatching")
     sys.exit(1 if bad else 0)
 

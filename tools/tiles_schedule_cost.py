@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""What the row-tile pipeline costs and what N GPUs could reach, measured on ONE GPU (DESIGN.md section 7).
+"""What the row-tile pipeline costs and what N GPUs could reach, measured on ONE GPU (DESIGN.md section 6).
 
 For every batch size: bench.py --mode tiles with one rank (the whole frame), with N ranks as threads of one process
 (--tile-ranks-in-process: every hand-over and gather in place as device copies, digests verified), and one rank of N alone with

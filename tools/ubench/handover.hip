@@ -1,5 +1,5 @@
 // Probe: what a per-row, both-ways hand-over between neighbouring workgroups costs on gfx950 -- the synchronisation a
-// row-synchronous sweep kernel (column strips marching down the rows, computing the three downward
+// row-synchronous sweep kernel (NOTES.md section 9: column strips marching down the rows, computing the three downward
 // directions together) would need at every row: a strip's first / last column of row r feeds the neighbouring strips' row r+1
 // in BOTH directions, so a chain of workgroups moves in lockstep.
 //
