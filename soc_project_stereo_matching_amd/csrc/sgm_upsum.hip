@@ -44,7 +44,8 @@ struct UpArgs {
     unsigned* progress;         // [B][ngroups]: (generation << 13) + iterations the workgroup's top team has published
     unsigned* ticket;           // [B], zero at launch: workgroups of a frame take their row group in arrival order
     int* status;                // pinned host word: set to 1 when a poll gave up (the maps are then wrong)
-    unsigned long long* trace;  // diagnostics (SGM_UPSUM_TRACE): [B][ngroups][4] 100 MHz timestamps: ticket drawn, first hand-over seen, last step done, xcc/cu id
+    unsigned long long* trace;  // diagnostics (SGM_UPSUM_TRACE): [B][ngroups][12]: 100 MHz timestamps (ticket drawn, first hand-over seen, last step done), xcc/cu id,
+                                // then shader-clock sums over the group's steps of wave 0: work before barrier A, wait at A, work before B, wait at B (bottom team), the same four for the top team
     unsigned gen;
     int W, H, D, dmin, B, p1, ngroups;
     int check_unique;
@@ -53,7 +54,7 @@ struct UpArgs {
 };
 
 #define UPSUM_MAX_EXTRA 8
-#define UPSUM_XC 48            // columns of an exchange ring (34 are live at any time)
+#define UPSUM_XC 36            // columns of an exchange ring (34 are live at any time)
 #define UPSUM_POLL_LIMIT (1u << 22)
 
 static __device__ __forceinline__ unsigned up_umad24(unsigned a, unsigned b, unsigned c) { return __umul24(a, b) + c; }
@@ -61,14 +62,19 @@ static __device__ __forceinline__ unsigned up_umad24(unsigned a, unsigned b, uns
 // One step of one direction with the matching cost already packed (shared by the three directions of a pixel): the
 // non-negative-P1 step of agg_step_nn -- L(d) = C(d) + min(min(Lp(d), Lp(d-1)+P1, Lp(d+1)+P1) - min_prev, P2') (ref :329-343) --
 // Cp = (C(2j), C(2j+1)) pairs, 127 where x - d is left of the image (census_costs).  Returns the new row minimum in both halves.
-template <int DPL, bool PAD, bool FAST>
+template <int DPL, int LPP, bool PAD, bool FAST>
 static __device__ __forceinline__ unsigned up_step(const us2 (&Cp)[DPL / 2], bool border, const us2 (&Lp)[DPL / 2], unsigned mp, unsigned pen32,
-                                                   unsigned p1u, const us2 (&padmask)[DPL / 2], unsigned (&sent)[2], us2 (&Ln)[DPL / 2])
+                                                   unsigned p1u, const us2 (&padmask)[DPL / 2], unsigned (&sent)[2], bool first_lane, bool last_lane,
+                                                   us2 (&Ln)[DPL / 2])
 {
     constexpr int NP = DPL / 2;
     const us2 p2v = as_p(pen32);
-    const unsigned from_left = sent[0] = dpp_mov<DPP_ROW_SHR1>(sent[0], as_u(Lp[NP - 1]));
-    const unsigned from_right = sent[1] = dpp_mov<DPP_ROW_SHL1>(sent[1], as_u(Lp[0]));
+    unsigned from_left = sent[0] = dpp_mov<DPP_ROW_SHR1>(sent[0], as_u(Lp[NP - 1]));
+    unsigned from_right = sent[1] = dpp_mov<DPP_ROW_SHL1>(sent[1], as_u(Lp[0]));
+    if (LPP != 16) {                                    // two pixels share a DPP row: cut the shift at the pixel boundary (255 sentinels, ref :260-263)
+        from_left = first_lane ? 0x00FF00FFu : from_left;
+        from_right = last_lane ? 0x00FF00FFu : from_right;
+    }
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         const unsigned below = (j == 0) ? from_left : as_u(Lp[j - 1]);
@@ -84,7 +90,7 @@ static __device__ __forceinline__ unsigned up_step(const us2 (&Cp)[DPL / 2], boo
         if (PAD) w |= as_u(padmask[j]);
         Ln[j] = as_p(w);
     }
-    return row_allmin_pk<16>(pk_min_tree<NP, FAST>(Ln));
+    return row_allmin_pk<LPP>(pk_min_tree<NP, FAST>(Ln));
 }
 
 template <int DPL>
@@ -100,8 +106,12 @@ static __device__ __forceinline__ void unpack_cells(const CellVec<DPL>& c, us2 (
 template <int DPL>
 static __device__ __forceinline__ void load_cells_sc1(const uint8_t* p, CellVec<DPL>& v)
 {
-    static_assert(DPL == 8 || DPL == 4, "hand-over cells are 8 or 4 bytes per lane");
-    if constexpr (DPL == 8) {
+    static_assert(DPL == 16 || DPL == 8 || DPL == 4, "hand-over cells are 16, 8 or 4 bytes per lane");
+    if constexpr (DPL == 16) {
+        const unsigned long long t0 = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t1 = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v.w[0] = (unsigned)t0; v.w[1] = (unsigned)(t0 >> 32); v.w[2] = (unsigned)t1; v.w[3] = (unsigned)(t1 >> 32);
+    } else if constexpr (DPL == 8) {
         const unsigned long long t = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         v.w[0] = (unsigned)t; v.w[1] = (unsigned)(t >> 32);
     } else {
@@ -111,7 +121,12 @@ static __device__ __forceinline__ void load_cells_sc1(const uint8_t* p, CellVec<
 template <int DPL>
 static __device__ __forceinline__ void store_cells_sc1(uint8_t* p, const CellVec<DPL>& v)
 {
-    if constexpr (DPL == 8)
+    if constexpr (DPL == 16) {
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v.w[0] | ((unsigned long long)v.w[1] << 32), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(p) + 1, (unsigned long long)v.w[2] | ((unsigned long long)v.w[3] << 32), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    } else if constexpr (DPL == 8)
         __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v.w[0] | ((unsigned long long)v.w[1] << 32), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     else
@@ -120,12 +135,16 @@ static __device__ __forceinline__ void store_cells_sc1(uint8_t* p, const CellVec
 
 // planes summed whole by this kernel (reference order ref :213-220: 0 (1,0), 1 (-1,0), 2 (0,1), 4 (1,1), 7 (-1,1)); 3 = (0,-1),
 // 5 = (-1,-1) and 6 = (1,-1) are the sweep computed here (5 and 6 are read in their post-wrap triangles only)
-template <int DPL, int R, bool PAD, bool FAST>
-__global__ __launch_bounds__(R * 256 + 64) void sgm_upsum_k(const UpArgs a)
+// LPP lanes per pixel x DPL disparities per lane = the padded range.  16 lanes is sgm_sum_wta_lr_k's layout; 8 lanes (16 disparities per
+// lane, a team = 2 waves) halves the wave instructions per pixel of everything that is per lane group -- the three direction steps
+// above all -- at the price of fewer waves per CU (the S rings of three rows fill its LDS either way).
+template <int DPL, int LPP, int R, bool PAD, bool FAST>
+__global__ __launch_bounds__(R * 16 * LPP + 64) void sgm_upsum_k(const UpArgs a)
 {
-    constexpr int Dp = 16 * DPL;
+    constexpr int Dp = LPP * DPL;
     constexpr int LD = Dp + 2;
     constexpr int COLS = 16;
+    constexpr int TEAM = COLS * LPP;                                     // threads of a team (one image row)
     constexpr int RC = Dp + COLS;                                        // TIGHT ring of sgm_sum_wta_lr_k: second barrier per step
     constexpr int MIR = DPL;
     constexpr int NP = DPL / 2;
@@ -143,13 +162,13 @@ __global__ __launch_bounds__(R * 256 + 64) void sgm_upsum_k(const UpArgs a)
 
     const int W = a.W, H = a.H, D = a.D, dmin = a.dmin;
     const int frame = blockIdx.x % a.B;
-    if (threadIdx.x < 256) lut32_s[threadIdx.x] = (unsigned)a.lut[threadIdx.x] * 0x00010001u;
+    for (int q = threadIdx.x; q < 256; q += R * TEAM + 64) lut32_s[q] = (unsigned)a.lut[q] * 0x00010001u;
     // A frame's row groups are taken in arrival order by the few workgroups the launch has per frame (a.ngroups of them would mostly
     // sit waiting for the rows below while holding a CU's LDS): whoever finishes a group takes the next one.  A group only ever
     // waits for the group before it, whose ticket was drawn earlier -- by a workgroup that is running or done.
     // The last wave of the workgroup computes nothing: it polls the progress word of the group below and publishes this group's.
     // Vector-memory results return in issue order, so a poll in a computing wave would drain that wave's plane prefetch every step.
-    const bool helper = threadIdx.x >= R * 256;
+    const bool helper = threadIdx.x >= R * TEAM;
     unsigned* const prog = a.progress + (size_t)frame * a.ngroups;
     const unsigned gen_base = a.gen << 13;
     const int x_last = a.do_right ? W - 1 + dmin + D - 1 : W - 1;        // last column any pixel of a row needs
@@ -164,9 +183,9 @@ __global__ __launch_bounds__(R * 256 + 64) void sgm_upsum_k(const UpArgs a)
     const int k = (int)group_s;                                          // row group, counted from the bottom of the image
     if (k >= a.ngroups) break;
     k_prev = k;
-    unsigned long long* const tr = a.trace ? a.trace + ((size_t)frame * a.ngroups + k) * 4 : nullptr;
+    unsigned long long* const tr = a.trace ? a.trace + ((size_t)frame * a.ngroups + k) * 12 : nullptr;
     if (helper) {
-        if (tr && threadIdx.x == R * 256) {
+        if (tr && threadIdx.x == R * TEAM) {
             tr[0] = __builtin_amdgcn_s_memrealtime();
             unsigned xcc, hw;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -188,24 +207,23 @@ __global__ __launch_bounds__(R * 256 + 64) void sgm_upsum_k(const UpArgs a)
                 }
             }
         };
-        wait_for(16);                                                    // iteration 0 of the bottom team reads columns -1 .. 16
-        if (tr && threadIdx.x == R * 256) tr[1] = __builtin_amdgcn_s_memrealtime();
+        wait_for(16 + 16);                                               // iterations 0 and 1 of the bottom team read columns -1 .. 32
+        if (tr && threadIdx.x == R * TEAM) tr[1] = __builtin_amdgcn_s_memrealtime();
         __syncthreads();
         for (int step = 0; step < n_steps; ++step) {
-            wait_for(16 * (step + 1) + 16);                              // what the bottom team prefetches behind barrier A: columns of iteration step + 1
+            wait_for(16 * (step + 2) + 16);                              // what the bottom team asks for at the START of the next step: iteration step + 2
             __syncthreads();                                             // A
-            // The top team's hand-over stores of step - 1 were issued before that step's barrier A and its census loads behind it;
-            // every wave of the team has consumed those loads by now, and vector-memory operations complete in issue order
-            if (step - R + 1 >= 1)
-                __hip_atomic_store(&prog[k], gen_base + (unsigned)(step - R + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();                                             // B
+            __syncthreads();                                             // B: every wave of the top team has seen its stores of this step complete
+            if (step - R + 2 >= 1)
+                __hip_atomic_store(&prog[k], gen_base + (unsigned)(step - R + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (tr && threadIdx.x == R * 256) tr[2] = __builtin_amdgcn_s_memrealtime();
+        if (tr && threadIdx.x == R * TEAM) tr[2] = __builtin_amdgcn_s_memrealtime();
         continue;
     }
-    const int t = threadIdx.x >> 8;                                      // team: 0 = the group's bottom row
-    const int tid = threadIdx.x & 255;
-    const int sub = tid & 15, px = tid >> 4;
+    const int t = threadIdx.x / TEAM;                                    // team: 0 = the group's bottom row
+    const int tid = threadIdx.x % TEAM;
+    const int sub = tid & (LPP - 1), px = tid / LPP;
+    const bool first_lane = sub == 0, last_lane = sub == LPP - 1;
     const int y = H - 1 - (k * R + t);
     const bool row_ok = y >= 0;
     const int yc = row_ok ? y : 0;
@@ -222,7 +240,7 @@ __global__ __launch_bounds__(R * 256 + 64) void sgm_upsum_k(const UpArgs a)
 
     // ---- second visits of the anomalous lines that land on this team's row (as in sgm_sum_wta_lr_k) ----
     const int n_extra = row_ok ? min(a.row_extra_count[yc], UPSUM_MAX_EXTRA) : 0;
-    for (int q = tid; q < n_extra * (Dp / 4); q += 256) {
+    for (int q = tid; q < n_extra * (Dp / 4); q += TEAM) {
         const int j = q / (Dp / 4), w = q % (Dp / 4);
         const sgmd_row_extra e = a.row_extras[yc * a.row_cap + j];
         if (w == 0) ex_col[t][j] = e.col_slot & 0xFFFF;
@@ -264,10 +282,10 @@ __global__ __launch_bounds__(R * 256 + 64) void sgm_upsum_k(const UpArgs a)
 
     // ---- prefetch state ----
     CellVec<DPL> pre[2][5], pre_ul[2], pre_ur[2];                        // planes of the iteration two steps ahead
-    CensusVec<DPL> cv;                                                   // census / grey / hand-over cells of the next iteration
-    unsigned cl;
-    uint8_t g_here, g_up, g_ul, g_ur;
-    CellVec<DPL> hin[3];                                                 // bottom team of a group above the first: L_r of the group below
+    CensusVec<DPL> cvb[2];                                               // census / grey of the iterations one and two steps ahead (as the planes)
+    unsigned clbuf[2];
+    uint8_t gb_here[2], gb_up[2], gb_ul[2], gb_ur[2];
+    CellVec<DPL> hinb[2][3];                                             // bottom team of a group above the first: L_r of the group below, one step ahead
     auto fetch_planes = [&](int stage, int x) {
         const unsigned off = cell_off(x);
 #pragma unroll
@@ -277,33 +295,43 @@ __global__ __launch_bounds__(R * 256 + 64) void sgm_upsum_k(const UpArgs a)
         load_cells<DPL>(pd_ul + ((xc >= tri_r) ? off : row_cells), pre_ul[stage]);
         load_cells<DPL>(pd_ur + ((xc < tri_l) ? off : row_cells), pre_ur[stage]);
     };
-    auto fetch_row = [&](int x) {
+    auto fetch_row = [&](int stage, int x) {
         const int xc = min(max(x, 0), W - 1);
         const unsigned p = row_pix + (unsigned)xc;
-        load_census<DPL>(reinterpret_cast<const uint32_t*>(crb + (size_t)((p + cbias) << 2)), cv);
-        cl = *reinterpret_cast<const uint32_t*>(clb + (size_t)(p << 2));
-        g_here = img[p];
-        g_up = img[below_pix + (unsigned)xc];
-        g_ul = img[below_pix + (unsigned)min(xc + 1, W - 1)];
-        g_ur = img[below_pix + (unsigned)max(xc - 1, 0)];
+        load_census<DPL>(reinterpret_cast<const uint32_t*>(crb + (size_t)((p + cbias) << 2)), cvb[stage]);
+        clbuf[stage] = *reinterpret_cast<const uint32_t*>(clb + (size_t)(p << 2));
+        gb_here[stage] = img[p];
+        gb_up[stage] = img[below_pix + (unsigned)xc];
+        gb_ul[stage] = img[below_pix + (unsigned)min(xc + 1, W - 1)];
+        gb_ur[stage] = img[below_pix + (unsigned)max(xc - 1, 0)];
     };
-    auto fetch_handover = [&](int x) {                                   // L_r(y+1, x), (y+1, x+1), (y+1, x-1) of directions 3, 5, 6
+    auto fetch_handover = [&](int stage, int x) {                                   // L_r(y+1, x), (y+1, x+1), (y+1, x-1) of directions 3, 5, 6
         const size_t dirb = (size_t)W * Dp;
         const unsigned c0 = (unsigned)min(max(x, 0), W - 1), c1 = (unsigned)min(max(x + 1, 0), W - 1), c2 = (unsigned)min(max(x - 1, 0), W - 1);
-        load_cells_sc1<DPL>(xb_in + (size_t)c0 * Dp + lane_off, hin[0]);
-        load_cells_sc1<DPL>(xb_in + dirb + (size_t)c1 * Dp + lane_off, hin[1]);
-        load_cells_sc1<DPL>(xb_in + 2 * dirb + (size_t)c2 * Dp + lane_off, hin[2]);
+        load_cells_sc1<DPL>(xb_in + (size_t)c0 * Dp + lane_off, hinb[stage][0]);
+        load_cells_sc1<DPL>(xb_in + dirb + (size_t)c1 * Dp + lane_off, hinb[stage][1]);
+        load_cells_sc1<DPL>(xb_in + 2 * dirb + (size_t)c2 * Dp + lane_off, hinb[stage][2]);
     };
     const bool from_global = (t == 0 && k > 0);
 
     __syncthreads();                                                     // ex_val / ex_col are in place, the helper has seen iteration 0's columns
     // issue order = the order of use: a load's data waits for every older load (vmcnt counts in issue order)
     fetch_planes(0, col_of(-t));
-    fetch_row(col_of(-t));
-    if (from_global) fetch_handover(col_of(-t));
+    fetch_row(0, col_of(-t));
+    if (from_global) fetch_handover(0, col_of(-t));
     fetch_planes(1, col_of(1 - t));
-    if (!from_global) { hin[0].w[0] = hin[1].w[0] = hin[2].w[0] = 0; if (NW > 1) { hin[0].w[NW - 1] = hin[1].w[NW - 1] = hin[2].w[NW - 1] = 0; } }
+    fetch_row(1, col_of(1 - t));
+    if (!from_global) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd)
+#pragma unroll
+                for (int w = 0; w < NW; ++w) hinb[q][dd].w[w] = 0;
+    }
 
+    unsigned long long ph[4] = {0, 0, 0, 0};                             // diagnostics: shader clocks per phase, summed over the steps
+    const bool timed = tr != nullptr && tid == 0 && (t == 0 || t == R - 1);
     int slot = px;                                                       // ring slot of this thread's column (advances 16 per step)
     unsigned sent[2] = {0x00FF00FFu, 0x00FF00FFu};
 
@@ -313,6 +341,10 @@ __global__ __launch_bounds__(R * 256 + 64) void sgm_upsum_k(const UpArgs a)
         const int x = col_of(i);
         const int xc = min(max(x, 0), W - 1);
         const bool inside = row_ok && x >= 0 && x < W;
+        const unsigned long long c0_ = tr ? __builtin_amdgcn_s_memtime() : 0;
+        // the helper saw the group below publish iteration i + 1's columns before the previous step ended: its cells are asked for now and
+        // used a whole step later
+        if (from_global) fetch_handover(STAGE ^ 1, col_of(i + 1));
         // ---- S = five planes + the sweep (+ anomalous visits): packed u16 pairs as in sgm_sum_wta_lr_k ----
         unsigned aL[NW], aH[NW];
 #pragma unroll
@@ -342,23 +374,23 @@ __global__ __launch_bounds__(R * 256 + 64) void sgm_upsum_k(const UpArgs a)
         us2 C[NP];
         const int lim = xc - lim_bias;
         const bool border = __any(lim < DPL - 1) != 0;
-        census_costs<DPL>(cl, cv, lim, border, C);
+        census_costs<DPL>(clbuf[STAGE], cvb[STAGE], lim, border, C);
         us2 Lup[NP], Lul[NP], Lur[NP];
         unsigned m_up, m_ul, m_ur;
         if (start) {
 #pragma unroll
             for (int j = 0; j < NP; ++j) Lup[j] = Lul[j] = Lur[j] = PAD ? as_p(as_u(C[j]) | as_u(padmask[j])) : C[j];
-            m_up = m_ul = m_ur = row_allmin_pk<16>(pk_min_tree<NP, FAST>(Lup));
+            m_up = m_ul = m_ur = row_allmin_pk<LPP>(pk_min_tree<NP, FAST>(Lup));
         } else {
             us2 Pup[NP], Pul[NP], Pur[NP];
             unsigned q_up, q_ul, q_ur;
             if (t == 0) {
-                unpack_cells<DPL>(hin[0], Pup);
-                unpack_cells<DPL>(hin[1], Pul);
-                unpack_cells<DPL>(hin[2], Pur);
-                q_up = row_allmin_pk<16>(pk_min_tree<NP, FAST>(Pup));
-                q_ul = row_allmin_pk<16>(pk_min_tree<NP, FAST>(Pul));
-                q_ur = row_allmin_pk<16>(pk_min_tree<NP, FAST>(Pur));
+                unpack_cells<DPL>(hinb[STAGE][0], Pup);
+                unpack_cells<DPL>(hinb[STAGE][1], Pul);
+                unpack_cells<DPL>(hinb[STAGE][2], Pur);
+                q_up = row_allmin_pk<LPP>(pk_min_tree<NP, FAST>(Pup));
+                q_ul = row_allmin_pk<LPP>(pk_min_tree<NP, FAST>(Pul));
+                q_ur = row_allmin_pk<LPP>(pk_min_tree<NP, FAST>(Pur));
             } else {
                 const int tp = (R > 1) ? t - 1 : 0;
                 const unsigned c0 = (unsigned)(x + 2 * UPSUM_XC) % XCN, c1 = (unsigned)(x + 1 + 2 * UPSUM_XC) % XCN,
@@ -377,13 +409,13 @@ __global__ __launch_bounds__(R * 256 + 64) void sgm_upsum_k(const UpArgs a)
                 q_ul = xmin[tp][1][c1];
                 q_ur = xmin[tp][2][c2];
             }
-            const unsigned g = g_here;
-            const unsigned pen_up = lut32_s[__builtin_amdgcn_sad_u8(g, (unsigned)g_up, 0u)];      // ref :335, |g - g_prev| of the visited pixels
-            const unsigned pen_ul = lut32_s[__builtin_amdgcn_sad_u8(g, (unsigned)g_ul, 0u)];
-            const unsigned pen_ur = lut32_s[__builtin_amdgcn_sad_u8(g, (unsigned)g_ur, 0u)];
-            m_up = up_step<DPL, PAD, FAST>(C, border, Pup, q_up, pen_up, p1u, padmask, sent, Lup);
-            m_ul = up_step<DPL, PAD, FAST>(C, border, Pul, q_ul, pen_ul, p1u, padmask, sent, Lul);
-            m_ur = up_step<DPL, PAD, FAST>(C, border, Pur, q_ur, pen_ur, p1u, padmask, sent, Lur);
+            const unsigned g = gb_here[STAGE];
+            const unsigned pen_up = lut32_s[__builtin_amdgcn_sad_u8(g, (unsigned)gb_up[STAGE], 0u)];      // ref :335, |g - g_prev| of the visited pixels
+            const unsigned pen_ul = lut32_s[__builtin_amdgcn_sad_u8(g, (unsigned)gb_ul[STAGE], 0u)];
+            const unsigned pen_ur = lut32_s[__builtin_amdgcn_sad_u8(g, (unsigned)gb_ur[STAGE], 0u)];
+            m_up = up_step<DPL, LPP, PAD, FAST>(C, border, Pup, q_up, pen_up, p1u, padmask, sent, first_lane, last_lane, Lup);
+            m_ul = up_step<DPL, LPP, PAD, FAST>(C, border, Pul, q_ul, pen_ul, p1u, padmask, sent, first_lane, last_lane, Lul);
+            m_ur = up_step<DPL, LPP, PAD, FAST>(C, border, Pur, q_ur, pen_ur, p1u, padmask, sent, first_lane, last_lane, Lur);
         }
         // ---- hand the new L_r to the row above: LDS inside the workgroup, the global hand-over row from the top team ----
         {
@@ -444,19 +476,20 @@ __global__ __launch_bounds__(R * 256 + 64) void sgm_upsum_k(const UpArgs a)
             key[2 * m + 1] = (pr[m] & 0xFFFF0000u) | (idx + 1);
             kmin = min(kmin, min(key[2 * m], key[2 * m + 1]));
         }
-        const unsigned kbest_l = row_allmin<16>(kmin);
+        const unsigned kbest_l = row_allmin<LPP>(kmin);
         unsigned k2 = 0xFFFFFFFFu;
         {
             const unsigned nbest = ~kbest_l;
 #pragma unroll
             for (int q = 0; q < DPL; ++q) k2 = min(k2, key[q] + nbest);
         }
-        const unsigned ksecond_l = row_allmin<16>(k2) + kbest_l + 1;
+        const unsigned ksecond_l = row_allmin<LPP>(k2) + kbest_l + 1;
 
+        const unsigned long long c1_ = tr ? __builtin_amdgcn_s_memtime() : 0;
         __syncthreads();                                                 // A: ring columns, exchange cells and the helper's poll are done
-        // ---- prefetch, in the order of use: census / grey / hand-over cells of the next iteration, then the planes of the one after ----
-        fetch_row(col_of(i + 1));
-        if (from_global) fetch_handover(col_of(i + 1));
+        const unsigned long long c2_ = tr ? __builtin_amdgcn_s_memtime() : 0;
+        // ---- prefetch for the iteration two steps ahead (this stage's registers are free again): census / grey, then the planes ----
+        fetch_row(STAGE, col_of(i + 2));
         fetch_planes(STAGE, col_of(i + 2));
 
         // ---- right view from the ring, then ONE wta_finish for both views (lane 0: left, lane 1: right) ----
@@ -479,13 +512,13 @@ __global__ __launch_bounds__(R * 256 + 64) void sgm_upsum_k(const UpArgs a)
                 key[q] = (!PAD || kk < D) ? ((val[q] << 16) | (unsigned)kk) : 0xFFFFFFFFu;
                 km = min(km, key[q]);
             }
-            const unsigned kb = row_allmin<16>(km);
+            const unsigned kb = row_allmin<LPP>(km);
             const unsigned nb = ~kb;
             unsigned k3 = 0xFFFFFFFFu;
 #pragma unroll
             for (int q = 0; q < DPL; ++q) k3 = min(k3, key[q] + nb);
             kbest_r = kb;
-            ksecond_r = row_allmin<16>(k3) + kb + 1;
+            ksecond_r = row_allmin<LPP>(k3) + kb + 1;
         }
         {
             const bool is_r = (sub == 1);
@@ -509,7 +542,16 @@ __global__ __launch_bounds__(R * 256 + 64) void sgm_upsum_k(const UpArgs a)
                 *out = wta_finish(st, D, dmin, a.check_unique, a.one_minus_ratio);
             }
         }
+        // The top team's hand-over stores were issued before barrier A; behind them this wave has issued at least 14 loads (fetch_row:
+        // >= 7, fetch_planes: 7).  Vector-memory operations complete in issue order, so once at most 12 are outstanding the stores
+        // are in L2 -- without draining the prefetch -- and the helper may publish this iteration behind barrier B.
+        if (t == R - 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        const unsigned long long c3_ = tr ? __builtin_amdgcn_s_memtime() : 0;
         __syncthreads();                                                 // B: every diagonal of this step has been read (TIGHT ring)
+        if (timed) {
+            const unsigned long long c4_ = __builtin_amdgcn_s_memtime();
+            ph[0] += c1_ - c0_; ph[1] += c2_ - c1_; ph[2] += c3_ - c2_; ph[3] += c4_ - c3_;
+        }
         slot += COLS;
         if (slot >= RC) slot -= RC;
     };
@@ -520,20 +562,24 @@ __global__ __launch_bounds__(R * 256 + 64) void sgm_upsum_k(const UpArgs a)
         body(step + 1, std::integral_constant<int, 1>{});
     }
     if (step < n_steps) body(step, std::integral_constant<int, 0>{});
+    if (timed) {
+        const int o = (t == 0) ? 4 : 8;
+        if (!(R == 1 && o == 8)) { tr[o] = ph[0]; tr[o + 1] = ph[1]; tr[o + 2] = ph[2]; tr[o + 3] = ph[3]; }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // this wave's hand-over stores are out before the group is called done
     }
 }
 
-template <int DPL, int R>
+template <int DPL, int LPP, int R>
 static void launch_upsum(const UpArgs& a, bool pad, bool fast, int wgs_per_frame, hipStream_t st)
 {
-    const dim3 grid((unsigned)(wgs_per_frame * a.B)), block(R * 256 + 64);
+    const dim3 grid((unsigned)(wgs_per_frame * a.B)), block(R * 16 * LPP + 64);
     if (pad) {
-        if (fast) hipLaunchKernelGGL((sgm_upsum_k<DPL, R, true, true>), grid, block, 0, st, a);
-        else      hipLaunchKernelGGL((sgm_upsum_k<DPL, R, true, false>), grid, block, 0, st, a);
+        if (fast) hipLaunchKernelGGL((sgm_upsum_k<DPL, LPP, R, true, true>), grid, block, 0, st, a);
+        else      hipLaunchKernelGGL((sgm_upsum_k<DPL, LPP, R, true, false>), grid, block, 0, st, a);
     } else {
-        if (fast) hipLaunchKernelGGL((sgm_upsum_k<DPL, R, false, true>), grid, block, 0, st, a);
-        else      hipLaunchKernelGGL((sgm_upsum_k<DPL, R, false, false>), grid, block, 0, st, a);
+        if (fast) hipLaunchKernelGGL((sgm_upsum_k<DPL, LPP, R, false, true>), grid, block, 0, st, a);
+        else      hipLaunchKernelGGL((sgm_upsum_k<DPL, LPP, R, false, false>), grid, block, 0, st, a);
     }
 }
 
@@ -592,7 +638,7 @@ int sgmd_upsum(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* path
     static const char* trace_path = getenv("SGM_UPSUM_TRACE");
     static unsigned long long* d_trace = nullptr;
     static size_t trace_cap = 0;
-    const size_t trace_n = (size_t)g->B * a.ngroups * 4;
+    const size_t trace_n = (size_t)g->B * a.ngroups * 12;
     a.trace = nullptr;
     if (trace_path && *trace_path) {
         if (trace_n > trace_cap) {
@@ -610,10 +656,19 @@ int sgmd_upsum(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* path
     static const int env_wgs = getenv("SGM_UPSUM_WGS") ? atoi(getenv("SGM_UPSUM_WGS")) : 0;
     int wgs = env_wgs > 0 ? env_wgs : (R == 1 ? 48 : 24);
     if (wgs > a.ngroups) wgs = a.ngroups;
-    switch (R) {
-    case 1: launch_upsum<8, 1>(a, pad, fast, wgs, st); break;
-    case 2: launch_upsum<8, 2>(a, pad, fast, wgs, st); break;
-    default: launch_upsum<8, 3>(a, pad, fast, wgs, st); break;
+    static const int env_lpp = getenv("SGM_UPSUM_LPP") ? atoi(getenv("SGM_UPSUM_LPP")) : 8;
+    if (env_lpp == 16) {
+        switch (R) {
+        case 1: launch_upsum<8, 16, 1>(a, pad, fast, wgs, st); break;
+        case 2: launch_upsum<8, 16, 2>(a, pad, fast, wgs, st); break;
+        default: launch_upsum<8, 16, 3>(a, pad, fast, wgs, st); break;
+        }
+    } else {
+        switch (R) {
+        case 1: launch_upsum<16, 8, 1>(a, pad, fast, wgs, st); break;
+        case 2: launch_upsum<16, 8, 2>(a, pad, fast, wgs, st); break;
+        default: launch_upsum<16, 8, 3>(a, pad, fast, wgs, st); break;
+        }
     }
     HIP_TRY(hipGetLastError());
     if (a.trace) {

@@ -134,6 +134,24 @@ def test_tile_mode_guards():
         i.close()
 
 
+def test_slot_engines_refuse_what_does_not_fit_before_allocating():
+    """Round 3's 2-rank rehearsal died inside hipMalloc on 34 GB of planes for one of seven slots.  Both hosts of the tile pipeline now
+    check sgm_tile_slot_bytes x slots against the free device memory first and say which batch would fit: the Python engine
+    (tiling.DeviceSlotEngine) raises, the C pipeline (sgm_tiles_create) returns NULL with the same message."""
+    import soc_project_stereo_matching_amd as S
+    from soc_project_stereo_matching_amd import tiles
+    from soc_project_stereo_matching_amd.tiling import DeviceSlotEngine, TilePipeline, tile_rows
+    w, h, d, world, batch = 3840, 2160, 128, 2, 16                  # 7 slots x 16 frames x 4.8 GB: over half a terabyte
+    opt = S.default_option(d)
+    slots = TilePipeline.slots_needed(world, 2)
+    need = tiles.slot_bytes(*tile_rows(h, world)[0], w, h, opt, batch) * slots
+    assert need > 500e9
+    with pytest.raises(RuntimeError, match=r"need about 5\d\d\.\d GB .* use a batch of at most \d+"):
+        DeviceSlotEngine(0, w, h, opt, tile_rows(h, world)[0], slots, host_staged=False, batch=batch)
+    with pytest.raises(RuntimeError, match="sgm_tiles_create failed"):
+        tiles.TilesPipeline(0, 0, world, w, h, opt, batch=batch, lead=2, transport=tiles.NullTransport().struct)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

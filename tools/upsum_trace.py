@@ -31,7 +31,7 @@ for rep in range(3):
     assert i.reset(w, h, opt) and i.match_device(L.data_ptr(), R.data_ptr(), out.data_ptr()) and i.synchronize()
 with open(path, "rb") as f:
     nb, ng, rows, _ = struct.unpack("4i", f.read(16))
-    t = np.frombuffer(f.read(), np.uint64).reshape(nb, ng, 4)
+    t = np.frombuffer(f.read(), np.uint64).reshape(nb, ng, 12)
 t0 = t[..., 0].astype(np.int64)
 tick = 0.01                                                      # 100 MHz -> us
 start = (t0 - t0.min()) * tick
@@ -49,4 +49,9 @@ fr = 0
 print("frame 0, groups 0..11: start / first hand-over seen after / duration (us)")
 for k in range(min(12, ng)):
     print(f"  {k:3d} {start[fr, k]:9.1f} {seen[fr, k]:8.2f} {dur[fr, k]:8.2f}  xcc {xcc[fr, k]}")
+steps = (w - 1 + d - 1 + rows - 1) // 16 + 1 + rows - 1
+for name, o in (("bottom team", 4), ("top team", 8)):
+    ph = t[..., o:o + 4].astype(np.float64) / steps                  # shader clocks per step
+    print(f"{name}, wave 0, shader clocks per step (mean over groups): work before barrier A {ph[..., 0].mean():7.0f}, wait at A {ph[..., 1].mean():7.0f}, "
+          f"work before B {ph[..., 2].mean():7.0f}, wait at B {ph[..., 3].mean():7.0f}   | group 0 of frame 0: {ph[0, 0].round().tolist()}")
 i.close()
