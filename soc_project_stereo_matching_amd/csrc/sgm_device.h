@@ -147,13 +147,14 @@ int sgmd_sum_wta_lr(int ord, void* stream, const sgmd_geom* g, int ndirs, const 
  * aggregation launch with paths->up_fused), writes the two disparity maps; S and the three planes never exist.
  * sgmd_upsum_rows: the most image rows a workgroup may take (sgmd_upsum's rows_per_workgroup: 1 .. that), 0 where the shape keeps the separate kernels (needs W > H, Dp = 128, whole frames).
  * scratch: sgmd_upsum_scratch_bytes(g) bytes, zero when allocated; generation: a different number for every launch on that scratch;
- * status: NULL or a page-locked int set to 1 if a workgroup gave up waiting for the rows below (the maps are then wrong). */
+ * status: NULL or a page-locked int set to 1 if a workgroup gave up waiting for the rows below (the maps are then wrong);
+ * workgroups_per_frame: 0 = the launcher's choice (a frame's row groups are drawn from a ticket by that many persistent workgroups). */
 int sgmd_upsum_rows(const sgmd_geom* g);
 size_t sgmd_upsum_scratch_bytes(const sgmd_geom* g);
 int sgmd_upsum(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* paths, const void* img_left, const void* census_l,
                const void* census_r, const void* lut, const void* planes, size_t plane_bytes, const void* extras,
                const void* row_extras, const void* row_extra_count, int row_cap, int do_right, int check_unique, float one_minus_ratio,
-               void* scratch, unsigned generation, void* status, int rows_per_workgroup, void* disp_l, void* disp_r);
+               void* scratch, unsigned generation, void* status, int rows_per_workgroup, int workgroups_per_frame, void* disp_l, void* disp_r);
 
 /* right-view winner-take-all on S[y][x+d][d] (SemiGlobalMatching.c:395-408) -> disp_r; needed by the LR check only */
 int sgmd_wta_right(int ord, void* stream, const sgmd_geom* g, const void* S, int check_unique, float one_minus_ratio,

@@ -53,7 +53,7 @@ struct sgm_instance {
     unsigned up_gen;             /* launch counter of the fused kernel (its progress words carry it) */
     int last_up_rows;            /* rows per workgroup of the fused sweep in the LAST match, 0 if it ran the separate kernels */
     bool planes_partial;         /* the planes of the last frame lack the upward directions: materialize_S re-creates them first */
-    int env_upsum, env_upsum_rows;   /* SGM_UPSUM, SGM_UPSUM_ROWS */
+    int env_upsum, env_upsum_rows, env_upsum_wgs;   /* SGM_UPSUM, SGM_UPSUM_ROWS, SGM_UPSUM_WGS */
     int env_lanes, env_hl, env_agg_fast, env_fused;   /* SGM_LANES_PER_PIXEL, SGM_HL, SGM_AGG_FAST, SGM_FUSED_WTA as read at sgm_create
                                     (-1: not set) -- tuning / test knobs, not looked up again on the per-frame sgm_reset path */
     bool stage_prio[3];          /* that stream was made by sgm_set_stage_priority (an all-CU request must replace it, not keep it) */
@@ -246,6 +246,7 @@ sgm_instance* sgm_create(int device)
     s->env_fused = env_int("SGM_FUSED_WTA");
     s->env_upsum = env_int("SGM_UPSUM");
     s->env_upsum_rows = env_int("SGM_UPSUM_ROWS");
+    s->env_upsum_wgs = env_int("SGM_UPSUM_WGS");
     return s;
 }
 
@@ -971,7 +972,7 @@ static bool run_pipeline(sgm_instance* s, const void* d_left, const void* d_righ
     if (use_up) {
         LAUNCH(sgmd_upsum(dev, sts, g, &s->paths, s->d_left_keep, s->d_census_l, s->d_census_r, s->d_lut, s->d_planes, s->plane_bytes, s->d_extras,
                           s->d_row_extras, s->d_row_count, s->row_cap, (o->is_check_lr || s->reference_view) ? 1 : 0, o->is_check_unique ? 1 : 0,
-                          1 - o->uniqueness_ratio, s->d_up_scratch, ++s->up_gen, s->h_status, s->up_rows, d_out, s->d_disp_r));
+                          1 - o->uniqueness_ratio, s->d_up_scratch, ++s->up_gen, s->h_status, s->up_rows, s->env_upsum_wgs > 0 ? s->env_upsum_wgs : 0, d_out, s->d_disp_r));
         s->planes_partial = true;                                /* S of this frame = five planes + what materialize_S re-creates */
         s->s_pending = true;
         s->s_pending_accumulate = false;

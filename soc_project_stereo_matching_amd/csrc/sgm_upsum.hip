@@ -601,7 +601,7 @@ size_t sgmd_upsum_scratch_bytes(const sgmd_geom* g)                      // hand
 int sgmd_upsum(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* paths, const void* img_left, const void* census_l,
                const void* census_r, const void* lut, const void* planes, size_t plane_bytes, const void* extras,
                const void* row_extras, const void* row_extra_count, int row_cap, int do_right, int check_unique, float one_minus_ratio,
-               void* scratch, unsigned generation, void* status, int rows, void* disp_l, void* disp_r)
+               void* scratch, unsigned generation, void* status, int rows, int wgs_per_frame, void* disp_l, void* disp_r)
 {
     HIP_TRY(hipSetDevice(ord));
     const int R = rows;
@@ -653,22 +653,14 @@ int sgmd_upsum(int ord, void* stream, const sgmd_geom* g, const sgmd_paths* path
     const bool fast = paths->allow_fast && paths->p1 <= 31488 && paths->pen_max <= 223;
     // workgroups per frame: what the chain of row groups can keep busy at once (steps of a group / steps between the starts of two
     // groups), not one per group -- the others would hold LDS waiting
-    static const int env_wgs = getenv("SGM_UPSUM_WGS") ? atoi(getenv("SGM_UPSUM_WGS")) : 0;
-    int wgs = env_wgs > 0 ? env_wgs : (R == 1 ? 48 : 24);
+    int wgs = wgs_per_frame > 0 ? wgs_per_frame : (R == 1 ? 48 : 16);
     if (wgs > a.ngroups) wgs = a.ngroups;
-    static const int env_lpp = getenv("SGM_UPSUM_LPP") ? atoi(getenv("SGM_UPSUM_LPP")) : 8;
-    if (env_lpp == 16) {
-        switch (R) {
-        case 1: launch_upsum<8, 16, 1>(a, pad, fast, wgs, st); break;
-        case 2: launch_upsum<8, 16, 2>(a, pad, fast, wgs, st); break;
-        default: launch_upsum<8, 16, 3>(a, pad, fast, wgs, st); break;
-        }
-    } else {
-        switch (R) {
-        case 1: launch_upsum<16, 8, 1>(a, pad, fast, wgs, st); break;
-        case 2: launch_upsum<16, 8, 2>(a, pad, fast, wgs, st); break;
-        default: launch_upsum<16, 8, 3>(a, pad, fast, wgs, st); break;
-        }
+    // 8 lanes per pixel x 16 disparities per lane (the 16-lane layout of sgm_sum_wta_lr_k measured the same per step with twice the
+    // instructions and spilled registers at three rows per workgroup: profiles/r04_fused_last_sweep.txt)
+    switch (R) {
+    case 1: launch_upsum<16, 8, 1>(a, pad, fast, wgs, st); break;
+    case 2: launch_upsum<16, 8, 2>(a, pad, fast, wgs, st); break;
+    default: launch_upsum<16, 8, 3>(a, pad, fast, wgs, st); break;
     }
     HIP_TRY(hipGetLastError());
     if (a.trace) {

@@ -171,9 +171,9 @@ int sgmd_upsum_rows(const sgmd_geom* g) { return (g->Dp == 128 && g->W > g->H &&
 size_t sgmd_upsum_scratch_bytes(const sgmd_geom* g) { return sgmd_upsum_rows(g) ? (size_t)g->B * 6 * g->W * g->Dp + 4096 : 0; }
 int sgmd_upsum(int o, void* st, const sgmd_geom* g, const sgmd_paths* p, const void* img, const void* cl, const void* cr, const void* lut,
                const void* pl, size_t pb, const void* ex, const void* re, const void* rc, int cap, int do_right, int cu, float omr,
-               void* scratch, unsigned gen, void* status, int rows, void* dl, void* dr)
+               void* scratch, unsigned gen, void* status, int rows, int wgs, void* dl, void* dr)
 { (void)o; (void)st; (void)g; (void)p; (void)img; (void)cl; (void)cr; (void)lut; (void)pl; (void)pb; (void)ex; (void)re; (void)rc; (void)cap;
-  (void)do_right; (void)cu; (void)omr; (void)scratch; (void)gen; (void)status; (void)dl; (void)dr;
+  (void)do_right; (void)cu; (void)omr; (void)scratch; (void)gen; (void)status; (void)wgs; (void)dl; (void)dr;
   return note("upsum", rows); }
 int sgmd_wta_right(int o, void* st, const sgmd_geom* g, const void* S, int cu, float omr, void* dr)
 { (void)o; (void)st; (void)g; (void)S; (void)cu; (void)omr; (void)dr; return note("wta_right", 0); }

@@ -212,6 +212,7 @@ def main():
         if mode == "upsum":                                   # read when the instance is created
             os.environ["SGM_UPSUM"] = "1"
             os.environ["SGM_UPSUM_ROWS"] = str(int(rng.integers(1, 4)))
+            os.environ["SGM_UPSUM_WGS"] = str(int(rng.choice([1, 2, 5, 16, 48])))
         win = (5, 5)
         if mode == "window":
             win = [(7, 7), (9, 7), (3, 5), (7, 9), (1, 1), (63, 1)][int(rng.integers(0, 6))]
@@ -272,7 +273,7 @@ def main():
         finally:
             inst.close()
             os.environ.pop("SGM_FUSED_WTA", None)
-            for k_ in ("SGM_UPSUM", "SGM_UPSUM_ROWS"):                   # (SGM_UPSUM_WGS is read once per process: set it outside)
+            for k_ in ("SGM_UPSUM", "SGM_UPSUM_ROWS", "SGM_UPSUM_WGS"):
                 os.environ.pop(k_, None)
             orc.set_census_window(5, 5)
             orc.set_reference_view(False)
