@@ -331,21 +331,9 @@ bool sgm_tiles_finish(sgm_tiles* t)
 
 /* ================================================================================================ RCCL transport */
 
-typedef struct { char internal[SGM_TILES_ID_BYTES]; } rccl_uid;      /* = ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES 128) */
-typedef struct {
-    void* lib;
-    int (*GetUniqueId)(rccl_uid*);
-    int (*CommInitRank)(void**, int, rccl_uid, int);
-    int (*CommDestroy)(void*);
-    int (*GroupStart)(void);
-    int (*GroupEnd)(void);
-    int (*Send)(const void*, size_t, int, int, void*, void*);
-    int (*Recv)(void*, size_t, int, int, void*, void*);
-    const char* (*GetErrorString)(int);
-} rccl_api;
+#include "sgm_rccl_abi.h"
 static rccl_api g_rccl;
 static pthread_mutex_t g_rccl_mu = PTHREAD_MUTEX_INITIALIZER;
-enum { RCCL_UINT8 = 1 };                                              /* ncclUint8 */
 
 static bool g_rccl_forced;                                            /* SGM_RCCL_LIBRARY names the library: bind to nothing else */
 static void* rccl_sym(const char* name)
