@@ -7,6 +7,9 @@
 #ifndef SGM_ANOM_PF
 #define SGM_ANOM_PF 4     // ... and for the anomalous diagonal lines (a kernel of their own: registers are no concern there)
 #endif
+#ifndef SGM_AGG_HBURST
+#define SGM_AGG_HBURST 1  // horizontal lines: L_r of this many consecutive steps are stored back to back (a burst of HBURST x 128 B per line); 1 = store every step
+#endif
 #ifndef SGM_AGG_PF_HL
 #define SGM_AGG_PF_HL 4   // the same for the 32- / 64-lane horizontal lines of a single frame (the launch's critical chain)
 #endif
@@ -510,8 +513,9 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
     unsigned sent[2] = {0x00FF00FFu, 0x00FF00FFu};                         // agg_step_nn's carried sentinel registers
     if constexpr (NN) min_prev |= min_prev << 16;                          // ... and its packed minimum
 
-    // one step on ring slot u; `refill` = also fetch step k + PF into the slot
-    auto step = [&](int u, bool refill) {
+    // one step on ring slot u; `refill` = also fetch step k + PF into the slot; `defer` != nullptr: hand the cells and their offset
+    // back instead of storing them (the horizontal lines' bursts)
+    auto step = [&](int u, bool refill, CellVec<DPL>* defer = nullptr, unsigned* defer_o = nullptr) {
         const int g = (int)gb[u];
         const int lim = limb[u];
         const unsigned o = ob[u];
@@ -542,7 +546,8 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
             min_prev = agg_step<DPL, PAD, LPP>(C, Lp, min_prev, lut_s[dg], p1v, padmask, first_lane, last_lane, packed);
         }
         g_prev = g;
-        if (st_ok) store_cells<DPL>(plane + o, packed);
+        if (defer) { *defer = packed; *defer_o = o; }
+        else if (st_ok) store_cells<DPL>(plane + o, packed);
     };
     // Everything the prologue has in flight lands before the hot loop (once per line).  The waits inside the loop are placed for
     // the state merged over BOTH ways into the loop head; with the prologue's loads still pending in whatever order the scheduler
@@ -550,6 +555,21 @@ static __device__ __forceinline__ void agg_regular(const AggArgs& a, const AggFr
     __builtin_amdgcn_s_waitcnt(0x0F70);                                     // vmcnt(0)
     // hot loop: all PF steps and all PF refills are in range, no per-step conditions
     int k0 = 1;
+    if constexpr (KIND == AGG_H && NN != 0 && SGM_AGG_HBURST > 1 && SGM_AGG_HBURST % PF == 0) {
+        // horizontal lines: a wave's lines are rows apart, so every step writes one 128-byte line per row; stored step by step those
+        // lines reach HBM microseconds apart, interleaved with thousands of other rows.  HBURST steps' cells go out back to back instead.
+        constexpr int HB = SGM_AGG_HBURST;
+        for (; k0 + HB + PF - 1 <= nsteps; k0 += HB) {
+            CellVec<DPL> pk[HB];
+            unsigned po[HB];
+#pragma unroll
+            for (int j = 0; j < HB; ++j) step(j % PF, true, &pk[j], &po[j]);
+            if (store_ok) {
+#pragma unroll
+                for (int j = 0; j < HB; ++j) store_cells<DPL>(plane + po[j], pk[j]);
+            }
+        }
+    }
     for (; k0 + 2 * PF - 1 <= nsteps; k0 += PF) {
 #pragma unroll
         for (int u = 0; u < PF; ++u) step(u, true);

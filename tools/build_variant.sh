@@ -9,6 +9,6 @@ out="$root/variants/$name"
 mkdir -p "$out/csrc"
 cp "$root"/soc_project_stereo_matching_amd/csrc/*.{hip,hpp,h,c} "$root"/soc_project_stereo_matching_amd/csrc/Makefile "$out/csrc/"
 mkdir -p "$out/include" && cp "$root"/include/*.h "$out/include/"
-sed -i "s#\.\./\.\./include#../include#g" "$out"/csrc/*.c "$out/csrc/Makefile"
+sed -i "s#\.\./\.\./include#../include#g" "$out"/csrc/*.c "$out"/csrc/*.h "$out/csrc/Makefile"
 make -s -C "$out/csrc" -j4 "$@" ../libsgm_mi355x.so
 echo "built $out/libsgm_mi355x.so ($*)"
