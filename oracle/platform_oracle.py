@@ -4,12 +4,14 @@ Nothing in the product imports this module; the product's implementations are th
 sgm_depth_k and sgm_score_k (csrc/sgm_post.hip) behind sgm_gray_from_planes / sgm_disparity_to_depth / sgm_compare_depth.
 Only tests/ and the test tools under tools/ use it, as the thing the device results are compared with.
 
-**Parity unpinned.**  The reference holds these formulas in HostScript_Server/depth_image.py (disparity_to_depth :138-165,
-compare_img :276-319), client.py:40-45 (the board simulator's depth conversion) and, for the grey conversion, in the firmware
-(ZedBoard/Vitis/lwip_tcp_perf_client/src/stereo_matching.c:18-25).  depth_image.py and client.py import cv2, which is not
-installed here (an ordinary ModuleNotFoundError), the firmware file needs Xilinx headers, and the reference ships no recorded
-depth maps or scores, so no reference-made vector exists: what follows restates the published formulas and says which
-arithmetic it assumes.
+**Parity: depth and scoring pinned since round 4, the grey conversion unpinned.**  The reference holds these formulas in
+HostScript_Server/depth_image.py (disparity_to_depth :138-165, compare_img :276-319), client.py:40-45 (the board simulator's depth
+conversion) and, for the grey conversion, in the firmware (ZedBoard/Vitis/lwip_tcp_perf_client/src/stereo_matching.c:18-25).
+depth_image.py and client.py import cv2, which is not installed here (an ordinary ModuleNotFoundError), and the firmware file needs
+Xilinx headers.  But disparity_to_depth and compare_img themselves are plain numpy: tests/golden/make_golden_depth.py compiles just
+those two definitions from the reference's text and runs them on the reference's own StereoCalib; tests/test_platform_oracle.py
+checks this restatement against what they returned (tests/golden/platform_depth.npz): bit-identical depth wherever the denominator is
+finite and non-zero, identical valid counts and bad-pixel rates, RMSE within 2e-6.  The grey formula has no reference-made vector.
 
 Assumed arithmetic (stated because NumPy 1.x and 2.x promote `python float * float32 array` differently):
   * depth: the calibration reaches the board as float32 values (the 80-byte block, stereo_calibration.py:177-195); the

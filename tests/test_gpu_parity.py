@@ -834,6 +834,37 @@ def test_depth_and_scoring_on_device(oracle):
         inst.close()
 
 
+def test_device_depth_and_scores_equal_the_references_own_functions():
+    """The same two device entries against vectors the REFERENCE'S OWN `disparity_to_depth` / `compare_img` produced
+    (tests/golden/platform_depth.npz; make_golden_depth.py compiles those two numpy-only functions from depth_image.py's text, the
+    module itself needs cv2): depth bit for bit wherever the denominator is finite and non-zero -- NaN by design elsewhere, where the
+    reference's bare formula gives 0 or inf --, valid count and bad-pixel rate exact, RMSE within 2e-6 relative (float32 pairwise mean
+    there, float64 sums here)."""
+    import torch
+    import soc_project_stereo_matching_amd as S
+    from test_platform_oracle import _depth_cases, check_depth_against_reference
+    z = load_npz("platform_depth.npz")
+    inst = S.SGMInstance(0)
+    try:
+        n = 0
+        for what, disp, fx, baseline, doffs, ref in _depth_cases():
+            t_disp = torch.from_numpy(np.ascontiguousarray(disp)).cuda()
+            t_depth = torch.empty_like(t_disp)
+            torch.cuda.synchronize()
+            assert inst.disparity_to_depth(t_disp.data_ptr(), disp.size, fx, baseline, doffs, t_depth.data_ptr()) and inst.synchronize()
+            check_depth_against_reference(t_depth.cpu().numpy(), disp, doffs, ref, what)
+            n += 1
+        assert n == 7
+        for k in range(int(z["n_scores"][0])):
+            t_gt, t_te = torch.from_numpy(z[f"score_{k}_gt"]).cuda(), torch.from_numpy(z[f"score_{k}_test"]).cuda()
+            torch.cuda.synchronize()
+            for rmse_r, bpr_r, n_r, thr in z[f"score_{k}_results"]:
+                rmse, bpr, nv = inst.compare_depth(t_gt.data_ptr(), t_te.data_ptr(), t_gt.numel(), float(thr))
+                assert nv == int(n_r) and abs(bpr - bpr_r) < 1e-12 and abs(rmse - rmse_r) <= 2e-6 * rmse_r, (k, thr, rmse, rmse_r)
+    finally:
+        inst.close()
+
+
 @pytest.mark.parametrize("split", [None, "post=0:4,main=4:28", "post=0:2,sum=2:10,main=12:20", "sum=0:0", "sum=0:8"])
 @pytest.mark.parametrize("batch", [1, 4])
 def test_overlapped_post_pass(oracle, batch, split):
