@@ -70,3 +70,18 @@ def test_firmware_side_constants_match_the_client():
     assert "uint8_t out[9] = {3," in client
     # message types the firmware accepts from the server
     assert "type == 1 || type == 2" in fw and "type == 3" in fw and "type == 0" in fw
+
+
+def test_firmware_grey_conversion_weights():
+    """stereo_matching.c:15-24 (the file needs Xilinx headers, so it is read, not built): grey = (76 R + 150 G + 29 B) >> 8 as uint8,
+    stored as float -- the weights of sgm_gray_planes_k's board mode, of oracle/platform_oracle.board_gray and of --placeholder-gray."""
+    import numpy as np
+    from oracle.platform_oracle import board_gray
+    fw = text(os.path.join(FW_SRC, "stereo_matching.c"))
+    m = re.search(r"uint32_t gray =\s*(\d+)u\s*\*[^;]*?left_red\[i\]\s*\+\s*(\d+)u\s*\*[^;]*?left_green\[i\]\s*\+\s*(\d+)u\s*\*[^;]*?left_blue\[i\];", fw, re.S)
+    assert m and tuple(int(v) for v in m.groups()) == (76, 150, 29)
+    assert "uint8_t gray8 = (uint8_t)(gray >> 8);" in fw and "depth[i] = (float)gray8;" in fw
+    r, g, b = np.array([255, 0, 13], np.uint8), np.array([255, 0, 200], np.uint8), np.array([255, 0, 77], np.uint8)
+    assert board_gray(b, g, r, 76).tolist() == [(76 * 255 + 150 * 255 + 29 * 255) >> 8, 0, (76 * 13 + 150 * 200 + 29 * 77) >> 8]
+    client = text(os.path.join(ROOT, "soc_project_stereo_matching_amd", "csrc", "sgm_board_client.c"))
+    assert "76" in client and "150" in client and "29" in client
