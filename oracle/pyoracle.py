@@ -296,6 +296,9 @@ class Reference:
         L.SGM_Match.restype = C.c_bool
         L.ref_run_stages.argtypes = [C.c_void_p, C.c_void_p, C.c_uint16, C.c_uint16, C.POINTER(SGMOption)] + [C.c_void_p] * 9
         L.ref_run_stages.restype = C.c_int
+        if hasattr(L, "ref_run_stages_first_dirs"):
+            L.ref_run_stages_first_dirs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint16, C.c_uint16, C.POINTER(SGMOption), C.c_int] + [C.c_void_p] * 9
+            L.ref_run_stages_first_dirs.restype = C.c_int
         L.ref_aggregate_dir.argtypes = [C.c_void_p, C.c_void_p, C.c_uint16, C.c_uint16, C.POINTER(SGMOption), C.c_int, C.c_int, C.c_void_p]
         L.ref_aggregate_dir.restype = C.c_int
         L.ref_oob_count.restype = C.c_ulong
@@ -308,7 +311,9 @@ class Reference:
         p = ref_path(w, h, d)
         return cls(p) if p else None
 
-    def run(self, left, right, opt):
+    def run(self, left, right, opt, first_dirs=None):
+        """All nine stages by the reference's own functions.  first_dirs = n: only the first n of the reference's eight CostAggregate
+        calls (SemiGlobalMatching.c:213-220) -- the 4-path mode as SURVEY.md Q1 defines it."""
         h, w = left.shape
         d = opt.max_disparity - opt.min_disparity
         out = {
@@ -319,8 +324,12 @@ class Reference:
             out[n] = np.zeros((h, w), np.float32)
         left = np.ascontiguousarray(left)
         right = np.ascontiguousarray(right)
-        rc = self.lib.ref_run_stages(left.ctypes.data, right.ctypes.data, w, h, C.byref(opt),
-                                     *[out[n].ctypes.data for n in STAGE_NAMES])
+        if first_dirs is None:
+            rc = self.lib.ref_run_stages(left.ctypes.data, right.ctypes.data, w, h, C.byref(opt),
+                                         *[out[n].ctypes.data for n in STAGE_NAMES])
+        else:
+            rc = self.lib.ref_run_stages_first_dirs(left.ctypes.data, right.ctypes.data, w, h, C.byref(opt), int(first_dirs),
+                                                    *[out[n].ctypes.data for n in STAGE_NAMES])
         if rc != 0:
             raise RuntimeError(f"ref_run_stages rc={rc}")
         if not opt.is_check_lr:

@@ -29,10 +29,14 @@ static int ref_fits(uint16_t w, uint16_t h, const SGMOption* o)
            o->max_disparity > o->min_disparity && (o->max_disparity - o->min_disparity) <= MAX_DISPARITY_RANGE;
 }
 
-/* Every out pointer may be NULL.  Returns 0 on success. */
-int ref_run_stages(const uint8_t* left, const uint8_t* right, uint16_t w, uint16_t h, const SGMOption* opt,
-                   uint32_t* census_l, uint32_t* census_r, uint8_t* cost, uint16_t* aggr,
-                   float* disp_l, float* disp_r, float* after_lr, float* after_speckle, float* final)
+/* Every out pointer may be NULL.  Returns 0 on success.
+ * first_dirs < 0: the reference's CostAggregation() as it stands (all eight CostAggregate calls, SemiGlobalMatching.c:213-220).
+ * first_dirs = n: only the FIRST n of those eight calls, in the reference's order -- what "num_paths == 4" means in this project
+ * (the reference never reads num_paths; the 4-path mode is defined as its first four calls, :213-216).  Every stage is
+ * still the reference's own function; only the selection of CostAggregate calls is the harness's. */
+static int run_stages(const uint8_t* left, const uint8_t* right, uint16_t w, uint16_t h, const SGMOption* opt, int first_dirs,
+                      uint32_t* census_l, uint32_t* census_r, uint8_t* cost, uint16_t* aggr,
+                      float* disp_l, float* disp_r, float* after_lr, float* after_speckle, float* final)
 {
     if (!ref_fits(w, h, opt)) return -1;
     ref_oob_dropped = 0;
@@ -48,7 +52,11 @@ int ref_run_stages(const uint8_t* left, const uint8_t* right, uint16_t w, uint16
     if (census_r) memcpy(census_r, sgm.census_right, px * 4);
     ComputeCost(sgm.census_left, sgm.census_right, sgm.cost_init);
     if (cost) memcpy(cost, sgm.cost_init, cells);
-    CostAggregation();
+    if (first_dirs < 0) CostAggregation();
+    else {
+        static const int8_t dir[8][2] = {{1, 0}, {-1, 0}, {0, 1}, {0, -1}, {1, 1}, {-1, -1}, {1, -1}, {-1, 1}};   /* .c:213-220 */
+        for (int d = 0; d < first_dirs && d < 8; ++d) CostAggregate(sgm.img_left, sgm.cost_init, sgm.cost_aggr, dir[d][0], dir[d][1]);
+    }
     if (aggr) memcpy(aggr, sgm.cost_aggr, cells * 2);
     ComputeDisparity(sgm.cost_aggr, sgm.disp_left, 0);
     if (disp_l) memcpy(disp_l, sgm.disp_left, px * 4);
@@ -63,6 +71,21 @@ int ref_run_stages(const uint8_t* left, const uint8_t* right, uint16_t w, uint16
     MedianFilter(sgm.disp_left, sgm.disp_left, FILTER_WINDOW_SIZE);
     if (final) memcpy(final, sgm.disp_left, px * 4);
     return 0;
+}
+
+int ref_run_stages(const uint8_t* left, const uint8_t* right, uint16_t w, uint16_t h, const SGMOption* opt,
+                   uint32_t* census_l, uint32_t* census_r, uint8_t* cost, uint16_t* aggr,
+                   float* disp_l, float* disp_r, float* after_lr, float* after_speckle, float* final)
+{
+    return run_stages(left, right, w, h, opt, -1, census_l, census_r, cost, aggr, disp_l, disp_r, after_lr, after_speckle, final);
+}
+
+int ref_run_stages_first_dirs(const uint8_t* left, const uint8_t* right, uint16_t w, uint16_t h, const SGMOption* opt, int first_dirs,
+                              uint32_t* census_l, uint32_t* census_r, uint8_t* cost, uint16_t* aggr,
+                              float* disp_l, float* disp_r, float* after_lr, float* after_speckle, float* final)
+{
+    if (first_dirs < 0 || first_dirs > 8) return -3;
+    return run_stages(left, right, w, h, opt, first_dirs, census_l, census_r, cost, aggr, disp_l, disp_r, after_lr, after_speckle, final);
 }
 
 /* One direction of CostAggregate on a caller-supplied cost volume, starting from S = 0. */

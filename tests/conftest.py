@@ -41,7 +41,8 @@ def oracle():
 def golden_cases():
     cases = {}
     # cases.json: make_golden.py; cases_scenes.json: make_golden_scenes.py (the reference's Cloth3 / Reindeer / Wood2 pairs)
-    for name in ("cases.json", "cases_scenes.json"):
+    # cases_paths4.json: make_golden_paths4.py (the 4-path mode = the reference's first four CostAggregate calls)
+    for name in ("cases.json", "cases_scenes.json", "cases_paths4.json"):
         with open(os.path.join(GOLDEN, name)) as f:
             cases.update({c["name"]: c for c in json.load(f)["cases"]})
     return cases
@@ -66,6 +67,10 @@ def case_inputs(case, oracle):
     from oracle.pyoracle import sha
     if case["name"] == "cone":
         z = load_npz("cone_inputs.npz")
+        return z["left"], z["right"]
+    if case.get("inputs_file") == "cone_inputs.npz":
+        z = load_npz("cone_inputs.npz")
+        assert sha(z["left"]) == case["sha256_inputs"]["left"]
         return z["left"], z["right"]
     if "file" in case or "inputs_file" in case:
         z = load_npz(case.get("file") or case["inputs_file"])

@@ -32,15 +32,15 @@ WORKLOADS = {
     "middlebury_2880x1988_d256_p8": (2880, 1988, 256, 0x5EED0003, range(4)),
     "uhd_3840x2160_d128_p8": (3840, 2160, 128, 0x5EED0006, range(8)),
     "uhd_3840x2160_d256_p8": (3840, 2160, 256, 0x5EED0007, range(4)),
-    # BASELINE config 1 says "4 paths": not a mode of the reference (num_paths is never read).  The library's
-    # 4-path extension is defined by oracle/sgm_oracle.c alone, so THESE digests are oracle-made: "4-path parity unpinned by the
-    # reference" -- they pin the bench's timed frames to the CPU restatement, nothing more.
+    # BASELINE config 1 says "4 paths": not a mode the reference can be asked for (num_paths is never read).  The mode is
+    # DEFINED as the first four of the reference's eight CostAggregate calls (SemiGlobalMatching.c:213-216); these digests come from
+    # the reference's own stage functions run with exactly those four calls (oracle/ref_harness_tail.c: ref_run_stages_first_dirs).
     "cone_450x375_d64_p4": (450, 375, 64, 0x5EED0001, range(16)),
     # throughput is reported with speckle removal on AND off; the same KITTI frames with is_remove_speckles = false
     # (main.c:60 flipped), so that the speckle-off rate is a verified one too
     "kitti_1242x375_d128_p8_nospeckle": (1242, 375, 128, 0x5EED0002, range(16)),
 }
-ORACLE_MADE = {"cone_450x375_d64_p4"}
+FIRST_FOUR_CALLS = {"cone_450x375_d64_p4"}
 SPECKLE_OFF = {"kitti_1242x375_d128_p8_nospeckle"}
 KEEP = ["disp_l", "disp_r", "after_lr", "after_speckle", "final"]
 
@@ -51,23 +51,20 @@ def one_frame(job):
     resource.setrlimit(resource.RLIMIT_STACK, (resource.RLIM_INFINITY, resource.RLIM_INFINITY))   # SemiGlobalMatching.c:588-589
     import numpy as np
     from oracle.pyoracle import Oracle, Reference, default_option, sha
-    if name in ORACLE_MADE:
-        orc = Oracle()
-        orc.set_honor_num_paths(True)
-        left, right = orc.synth_pair(w, h, d, seed)
-        t0 = time.time()
-        st = orc.run(left, right, default_option(d, num_paths=4))
-        return name, seed, {"sha256": {n: sha(st[n]) for n in KEEP}, "sha256_inputs": {"left": sha(left), "right": sha(right)},
-                            "invalid_final": int(np.isinf(st["final"]).sum()), "made_by": "oracle/sgm_oracle.c (4 paths: no reference mode)",
-                            "reference_seconds": round(time.time() - t0, 1)}
     ref = Reference.for_shape(w, h, d)
     assert ref is not None, f"oracle/build_ref.sh {w} {h} {d} first"
     left, right = Oracle().synth_pair(w, h, d, seed)
     t0 = time.time()
-    st = ref.run(left, right, default_option(d, is_remove_speckles=False) if name in SPECKLE_OFF else default_option(d))
-    return name, seed, {"sha256": {n: sha(st[n]) for n in KEEP}, "sha256_inputs": {"left": sha(left), "right": sha(right)},
-                        "invalid_final": int(np.isinf(st["final"]).sum()), "oob_dropped": ref.oob_count(),
-                        "reference_seconds": round(time.time() - t0, 1)}
+    if name in FIRST_FOUR_CALLS:
+        st = ref.run(left, right, default_option(d, num_paths=4), first_dirs=4)
+    else:
+        st = ref.run(left, right, default_option(d, is_remove_speckles=False) if name in SPECKLE_OFF else default_option(d))
+    entry = {"sha256": {n: sha(st[n]) for n in KEEP}, "sha256_inputs": {"left": sha(left), "right": sha(right)},
+             "invalid_final": int(np.isinf(st["final"]).sum()), "oob_dropped": ref.oob_count(),
+             "reference_seconds": round(time.time() - t0, 1)}
+    if name in FIRST_FOUR_CALLS:
+        entry["made_by"] = "the reference's stage functions with the first four CostAggregate calls (ref_run_stages_first_dirs)"
+    return name, seed, entry
 
 
 def main():
@@ -82,7 +79,7 @@ def main():
         w, h, d, seed, frames = WORKLOADS[n]
         old = {} if force else doc["workloads"].get(n, {}).get("frames", {})
         doc["workloads"][n] = {"w": w, "h": h, "d": d, "first_seed": seed,
-                               "option": "main.c:48-65 with max_disparity = D" + (", num_paths = 4 honoured" if n in ORACLE_MADE else "")
+                               "option": "main.c:48-65 with max_disparity = D" + (", num_paths = 4 honoured = the reference's first four CostAggregate calls" if n in FIRST_FOUR_CALLS else "")
                                          + (", is_remove_speckles = false" if n in SPECKLE_OFF else ""),
                                "frames": dict(old)}
         jobs += [(n, w, h, d, seed + k) for k in frames if str(seed + k) not in old]     # only what is missing (--force: all)

@@ -135,9 +135,30 @@ def test_q14_match_without_reset_accumulates(gsgm, fused, monkeypatch):
     assert_same(gsgm.match(z["left2"], z["right2"]), z["second_fresh"], "second after reset")
 
 
+@pytest.mark.parametrize("name", ["p4_cone", "p4_scene_reindeer", "p4_t70x33_d16", "p4_t20x31_d8_tall", "p4_t40x24_d16_dmin3",
+                                  "p4_kitti_1242x375_d128"])
+def test_four_path_mode_equals_the_references_first_four_calls(inst, oracle, golden_cases, name):
+    """BASELINE config 0 ("4 paths"): num_paths == 4 with SGM_SetHonorNumPaths(1) against digests of the reference's OWN stage functions
+    run with the first four of its eight CostAggregate calls (SemiGlobalMatching.c:213-216; tests/golden/cases_paths4.json) -- every
+    stage the device materialises, on the cone pair, a real scene, tiny / tall / dmin shapes and a KITTI-size frame."""
+    case = golden_cases[name]
+    left, right = case_inputs(case, oracle)
+    inst.set_honor_num_paths(True)
+    try:
+        assert inst.reset(case["w"], case["h"], option_from_dict(case["option"]))
+        out = inst.match(left, right)
+        assert out is not None
+        st = inst.read_stages()
+        for n in STAGE_NAMES:
+            assert sha(st[n]) == case["sha256"][n], f"{name}: stage {n} differs from the reference's four-call run"
+        assert sha(out) == case["sha256"]["final"]
+    finally:
+        inst.set_honor_num_paths(False)
+
+
 def test_four_path_mode_extension(inst, oracle):
-    """num_paths == 4 with SGM_SetHonorNumPaths(1): the first four directions only.  The reference
-    ignores num_paths (Q1), so this mode is pinned by the oracle alone ('4-path parity unpinned')."""
+    """num_paths == 4 with SGM_SetHonorNumPaths(1): the first four directions only, here against the oracle on a further shape (the
+    reference-made digests of this mode: test_four_path_mode_equals_the_references_first_four_calls)."""
     from oracle.pyoracle import default_option
     left, right = oracle.synth_pair(450, 375, 64, 0x5EED0001)
     opt = default_option(64, num_paths=4)
